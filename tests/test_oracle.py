@@ -1,0 +1,61 @@
+"""CPU: pins the C oracle (oracle/gliclass_oracle.c) on the HF-generated golden fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*_b*_s*.npz")))
+
+
+def test_delta_table_bit_exact(golden_dir):
+    """The log-bucket table must match torch's float32 arithmetic bit for bit (SURVEY.md §7 hard part 2)."""
+    tabs = np.load(os.path.join(golden_dir, "delta_tables.npz"))
+    for key in tabs.files:
+        S = int(key[1:])
+        got = oracle_c.delta_table(S)
+        assert np.array_equal(got, tabs[key].astype(np.int32)), key
+    t = oracle_c.delta_table(1024)
+    assert t[1023] == 256 and t[0] == 0 and t[-1] == 511          # clamp asymmetry for S > 512
+    assert t[1023 + 127] == 383 and t[1023 - 127] == 129          # identity region edge
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_golden(case, golden_dir, weights_for):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    cfg, w = weights_for(str(g["config"]))
+    ids, mask = g["ids"].astype(np.int64), g["mask"].astype(np.int64)
+    logits, hidden = oracle_c.forward(cfg, w, ids, mask, want_hidden=True)
+    assert logits.shape == g["logits"].shape
+    np.testing.assert_allclose(logits, g["logits"], atol=1e-4, rtol=0)   # fp32 summation-order noise; bar is 1e-3
+    probs = 1.0 / (1.0 + np.exp(-logits.astype(np.float64)))
+    np.testing.assert_allclose(probs, g["probs"], atol=3e-5, rtol=0)
+    pos = g["sample_pos"]
+    hs = g["hidden_samples"]
+    got = hidden[:, :, pos, :][..., : hs.shape[-1]][:, :, : hs.shape[2]]
+    valid = mask[:, pos][:, : hs.shape[2]].astype(bool)
+    np.testing.assert_allclose(got[:, valid], hs[:, valid], atol=2e-4, rtol=0)
+    s = np.abs(hidden * mask[None, :, :, None]).sum(axis=(2, 3))
+    np.testing.assert_allclose(s, g["hidden_abs_sum"], rtol=1e-5)
+
+
+def test_oracle_edge_cases(weights_for):
+    """Ragged C, a row without labels, S=1-token-after-prefix, all-padding tail."""
+    from gliclass.c_amd import synth
+    cfg, w = weights_for("tiny")
+    ids, mask, counts = synth.make_inputs(cfg, 3, 40, 3, ragged=True, labels_per_row=[3, 0, 1])
+    assert list(counts) == [3, 0, 1]
+    logits = oracle_c.forward(cfg, w, ids, mask)
+    assert logits.shape == (3, 3) and np.isfinite(logits).all()
+    # rows are independent: running row 2 alone (trimmed to its own length) gives the same logits
+    n = int(mask[2].sum())
+    solo = oracle_c.forward(cfg, w, ids[2:3, :n], mask[2:3, :n])
+    np.testing.assert_allclose(solo[0, :1], logits[2, :1], atol=2e-5)
+
+
+def test_sigmoid_matches_reference_formula():
+    lib = oracle_c.lib()
+    for x in (-20.0, -1.5, 0.0, 0.3, 7.0):
+        assert abs(lib.glo_sigmoid(x) - 1.0 / (1.0 + np.exp(-x))) < 1e-7

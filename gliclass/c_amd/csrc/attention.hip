@@ -1,0 +1,244 @@
+// DeBERTa-v2/v3 disentangled self-attention (modeling_deberta_v2.py:229-345), re-derived for gfx950.
+//
+// Algebra.  With share_att_key, pos_att_type = c2p|p2c and rel(q,k) = bucket(q-k) (an odd function,
+// :57-69), both relative-position terms use ONE index that depends on q-k only:
+//     delta(q-k) = clamp(bucket(q-k) + span, 0, 2 span - 1)
+//     score[q,k] = ( Q_q.K_k  +  Q_q.PK[delta(q-k)]  +  K_k.PQ[delta(q-k)] ) / sqrt(3 d)
+// (c2p: :315-324, p2c: :327-343 — the p2c gather index clamp(-bucket(k-q)+span) equals delta(q-k)).
+// 1/sqrt(3d) is folded into Wq at load time, so Q and PQ = query_proj(rel) arrive pre-scaled.
+// Key padding (masked_fill(finfo.min), :256-257) is an additive per-key bias of -1e30; rows whose
+// query is padding are don't-care (they never feed a valid row).
+//
+// attn_band_kernel (16-bit operands): one wave owns a 32-query tile and walks 32-key tiles with an
+// online softmax, all on 32x32x16 MFMA:
+//   S^T  = K_tile Q^T                    (keys on rows -> each lane holds 16 keys of ONE query)
+//   c2p  : B^T[rr][q]  = PK[delta(rmin+rr)] . Q_q     rr = 0..63  ("Toeplitz band": rr = q-k-rmin)
+//   p2c  : B [rr][k]   = PQ[delta(rmin+rr)] . K_k
+//   O^T += V^T_tile P^T                  (P^T taken straight from the S^T accumulators)
+// The position operand rows are gathered by delta at fragment-load time, so the band is indexed by
+// the relative distance itself and the per-element lookup is pure arithmetic (rr = c - kk + 31).
+// Both bands go through a wave-private LDS scratch (2 x 32 x 68 floats) — written as b128 rows,
+// read back as conflict-free b32 gathers; no workgroup barrier anywhere in the kernel.
+// Key rows are loaded in the order pi(r) = swap(bit2,bit3) so that the accumulator-as-operand k
+// permutation of the P*V MFMA lines up with 8 CONTIGUOUS keys of V^T (one 16-B load per lane).
+#include "glc_common.h"
+#include "glc_kernels.h"
+
+namespace {
+
+constexpr int LROW = 68;  // floats per LDS band row (64 + 4 pad: 16-B aligned rows, odd multiple of 4 banks)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_band_kernel(AttnArgs a) {
+    typedef typename Frag<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int Sp = a.Sp;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= Sp) return;                      // whole wave leaves; no workgroup barriers below
+    const int bh = blockIdx.y, b = bh / a.nh, hh = bh - b * a.nh;
+
+    const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64;
+    const T* __restrict__ Kp = reinterpret_cast<const T*>(a.Kh) + (size_t)bh * Sp * 64;
+    const T* __restrict__ Vp = reinterpret_cast<const T*>(a.Vt) + (size_t)bh * 64 * Sp;
+    const T* __restrict__ PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64;
+    const T* __restrict__ PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64;
+    const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
+    const int32_t* __restrict__ dtab = a.dtab;
+    float* c2p_l = lds + (size_t)wave * 2 * 32 * LROW;
+    float* p2c_l = c2p_l + 32 * LROW;
+
+    frag_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag_t*>(Qp + c * 64 + 16 * s + 8 * h);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    const int pr = (c & 0x13) | ((c & 4) << 1) | ((c & 8) >> 1);   // pi(c)
+    int nkt = (a.klen[b] + 31) >> 5;                               // key tiles beyond the last valid key add exactly 0
+    nkt = nkt < 1 ? 1 : (nkt > (Sp >> 5) ? (Sp >> 5) : nkt);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k0 = kt * 32;
+        frag_t kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag_t*>(Kp + (size_t)(k0 + pr) * 64 + 16 * s + 8 * h);
+
+        // S^T accumulators start from the additive key bias: reg i <-> key k0 + 16*(i>>3) + 8h + (i&7)
+        f32x16 sacc;
+        {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + 8 * h);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + 8 * h + 4);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + 8 * h);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + 8 * h + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sacc[i] = b0[i]; sacc[4 + i] = b1[i]; sacc[8 + i] = b2[i]; sacc[12 + i] = b3[i]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+
+        // relative-position bands over rr = (q-k) - rmin, rmin = q0 - k0 - 31
+        const int rmin = q0 - k0 - 31;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            int idx = rmin + 32 * jt + c + Sp - 1;
+            idx = idx < 0 ? 0 : (idx > 2 * Sp - 2 ? 2 * Sp - 2 : idx);
+            const int dl = dtab[idx];
+            frag_t pf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const frag_t*>(PKp + (size_t)dl * 64 + 16 * s + 8 * h);
+            f32x16 bacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pf[s], qf[s], bacc);          // [rr][query c]
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(c2p_l + c * LROW + 32 * jt + 8 * g + 4 * h) =
+                    (f32x4){bacc[4 * g], bacc[4 * g + 1], bacc[4 * g + 2], bacc[4 * g + 3]};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const frag_t*>(PQp + (size_t)dl * 64 + 16 * s + 8 * h);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pf[s], kf[s], bacc);          // [rr][key pi(c)]
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(p2c_l + pr * LROW + 32 * jt + 8 * g + 4 * h) =
+                    (f32x4){bacc[4 * g], bacc[4 * g + 1], bacc[4 * g + 2], bacc[4 * g + 3]};
+        }
+        wave_lds_sync();
+
+        float sv[16];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = 16 * (i >> 3) + 8 * h + (i & 7);
+            const int rr = c - kk + 31;
+            sv[i] = sacc[i] + c2p_l[c * LROW + rr] + p2c_l[kk * LROW + rr];
+            mx = fmaxf(mx, sv[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __expf(m - mnew);
+        m = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sv[i] = __expf(sv[i] - mnew); psum += sv[i]; }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            frag_t pfr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+            const frag_t v0 = *reinterpret_cast<const frag_t*>(Vp + (size_t)c * Sp + k0 + 16 * t + 8 * h);
+            const frag_t v1 = *reinterpret_cast<const frag_t*>(Vp + (size_t)(32 + c) * Sp + k0 + 16 * t + 8 * h);
+            mma32(v0, pfr, o0);       // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
+            mma32(v1, pfr, o1);       //                   dd + 32
+        }
+        wave_lds_sync();              // this tile's gathers retire before the next tile's band writes
+    }
+
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    T* out = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + c) * a.H + hh * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        store4<T>(out + 8 * g + 4 * h, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        store4<T>(out + 32 + 8 * g + 4 * h, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+}
+
+// Straightforward kernel (any T, no MFMA): one block per (query, batch*head).  fp32 path and the
+// on-device cross-check of the band kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qv = sm;            // [64]
+    float* red = sm + 64;      // [256]
+    float* sc = sm + 64 + 256; // [Sp]
+    const int Sp = a.Sp, q = blockIdx.x, bh = blockIdx.y, b = bh / a.nh, hh = bh - b * a.nh;
+    const int t = threadIdx.x;
+    const T* Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q) * 64;
+    const T* Kp = reinterpret_cast<const T*>(a.Kh) + (size_t)bh * Sp * 64;
+    const T* Vp = reinterpret_cast<const T*>(a.Vt) + (size_t)bh * 64 * Sp;
+    const T* PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64;
+    const T* PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64;
+    const float* kb = a.kbias + (size_t)b * Sp;
+    if (t < 64) qv[t] = (float)Qp[t];
+    __syncthreads();
+    float mx = -3.0e38f;
+    for (int k = t; k < Sp; k += 256) {
+        const int dl = a.dtab[q - k + Sp - 1];
+        const T* kr = Kp + (size_t)k * 64;
+        const T* pk = PKp + (size_t)dl * 64;
+        const T* pq = PQp + (size_t)dl * 64;
+        float s = 0.f;
+        for (int e = 0; e < 64; ++e) {
+            const float kv = (float)kr[e];
+            s += qv[e] * (kv + (float)pk[e]) + kv * (float)pq[e];
+        }
+        s += kb[k];
+        sc[k] = s;
+        mx = fmaxf(mx, s);
+    }
+    red[t] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int k = t; k < Sp; k += 256) { const float p = __expf(sc[k] - mx); sc[k] = p; sum += p; }
+    red[t] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const float inv = 1.0f / red[0];
+    __syncthreads();
+    const int dd = t & 63, part = t >> 6;
+    const int per = (Sp + 3) / 4, klo = part * per, khi = min(Sp, klo + per);
+    float acc = 0.f;
+    const T* vr = Vp + (size_t)dd * Sp;
+    for (int k = klo; k < khi; ++k) acc += sc[k] * (float)vr[k];
+    red[t] = acc;
+    __syncthreads();
+    if (t < 64) {
+        const float v = (red[t] + red[t + 64] + red[t + 128] + red[t + 192]) * inv;
+        reinterpret_cast<T*>(a.CTX)[((size_t)b * Sp + q) * a.H + hh * 64 + t] = (T)v;
+    }
+}
+
+}  // namespace
+
+// Shape contract: head_dim == 64, Sp % 64 == 0, H == nh*64, dtab has 2*Sp-1 entries in [0, P).
+const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a) {
+    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.CTX) return "attention: null pointer";
+    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0) return "attention: bad shape";
+    if (impl == 2 && dtype == GLC_DT_F32) return "attention: the MFMA band kernel needs 16-bit operands";
+    if (impl == 2) {
+        dim3 grid((a.Sp / 32 + 3) / 4, a.B * a.nh), block(256);
+        if (dtype == GLC_DT_BF16) hipLaunchKernelGGL(attn_band_kernel<bf16_t>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(attn_band_kernel<f16_t>, grid, block, 0, st, a);
+        return nullptr;
+    }
+    const size_t shm = (size_t)(64 + 256 + a.Sp) * sizeof(float);
+    if (shm > 64 * 1024) return "attention(simple): sequence too long for the reference kernel";
+    dim3 grid(a.Sp, a.B * a.nh), block(256);
+    switch (dtype) {
+        case GLC_DT_F32: hipLaunchKernelGGL(attn_simple_kernel<float>, grid, block, shm, st, a); break;
+        case GLC_DT_BF16: hipLaunchKernelGGL(attn_simple_kernel<bf16_t>, grid, block, shm, st, a); break;
+        case GLC_DT_F16: hipLaunchKernelGGL(attn_simple_kernel<f16_t>, grid, block, shm, st, a); break;
+        default: return "attention: bad dtype";
+    }
+    return nullptr;
+}

@@ -1,0 +1,521 @@
+// Engine = what g_ort->CreateSession + g_ort->Run are to /root/reference/src/model.c:173,269:
+// weight residency in HBM, workspace management, and the per-forward launch sequence on ONE HIP
+// stream.  Implements include/gliclass_hip.h.  No CPU fallback exists: without a GPU every entry
+// point fails loudly through glc_last_error().
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/gliclass_hip.h"
+#include "glc_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string& s) { g_err = s; }
+
+#define HIPCHK(expr, ret)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            set_err(std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+            return ret;                                                                            \
+        }                                                                                          \
+    } while (0)
+#define KCHK(expr, ret)                                                                            \
+    do {                                                                                           \
+        const char* _m = (expr);                                                                   \
+        if (_m) { set_err(_m); return ret; }                                                       \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t esize(int dtype) { return dtype == GLC_F32 ? 4 : 2; }
+
+enum { PC_SCAN = 0, PC_EMBED, PC_QKV, PC_ATTN, PC_ATTN_OUT, PC_LN, PC_FFN1, PC_FFN2, PC_HEAD, PC_N };
+const char* const kProfNames[PC_N] = {"scan_rows", "embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm",
+                                      "gemm_ffn1_gelu", "gemm_ffn2", "head"};
+
+struct LayerW {
+    void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;       // T
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;       // f32
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; // f32
+    void *PK = nullptr, *PQ = nullptr;                                        // T [nh, P, 64]
+};
+
+}  // namespace
+
+struct glc_engine {
+    glc_model_config cfg{};
+    int dtype = GLC_F32, device = 0, attn_impl = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::vector<void*> allocs;      // everything freed at destroy
+    // weights
+    void* emb = nullptr; float *eln_g = nullptr, *eln_b = nullptr;
+    std::vector<LayerW> layers;
+    float* headw[8] = {nullptr};
+    int P = 0;
+    // workspace
+    int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0;
+    void *X = nullptr, *Qh = nullptr, *Kh = nullptr, *Vt = nullptr, *CTX = nullptr, *T1 = nullptr, *H1 = nullptr, *FF = nullptr;
+    float* kbias = nullptr; int *klen = nullptr, *cls_pos = nullptr, *cls_cnt = nullptr;
+    int64_t *d_ids = nullptr, *d_mask = nullptr;
+    float *Gt = nullptr, *Gc = nullptr, *G1t = nullptr, *G1c = nullptr, *G2t = nullptr, *G2c = nullptr, *d_logits = nullptr;
+    std::map<int, int32_t*> dtabs;
+    // last forward
+    int lastB = 0, lastS = 0, lastSp = 0;
+    // debug
+    bool keep_hidden = false; void* hidden_dump = nullptr; size_t hidden_cap = 0;
+    // timing / profile
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> evs; size_t ev_used = 0;
+    float prof_ms[PC_N] = {0}; int prof_n[PC_N] = {0};
+};
+
+namespace {
+
+void* dmalloc(glc_engine* e, size_t bytes, bool zero = true) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_err("hipMalloc failed for " + std::to_string(bytes) + " bytes"); return nullptr; }
+    if (zero && hipMemsetAsync(p, 0, bytes, e->stream) != hipSuccess) { set_err("hipMemset failed"); return nullptr; }
+    e->allocs.push_back(p);
+    return p;
+}
+void dfree(glc_engine* e, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < e->allocs.size(); ++i)
+        if (e->allocs[i] == p) { e->allocs[i] = e->allocs.back(); e->allocs.pop_back(); break; }
+    (void)hipFree(p);
+}
+
+struct Prof {
+    glc_engine* e; int idx = -1;
+    Prof(glc_engine* e_, int cls) : e(e_) {
+        if (!e->profile) return;
+        if (e->ev_used == e->evs.size()) {
+            glc_engine::Ev v{};
+            if (hipEventCreate(&v.a) != hipSuccess || hipEventCreate(&v.b) != hipSuccess) return;
+            e->evs.push_back(v);
+        }
+        idx = (int)e->ev_used++;
+        e->evs[idx].cls = cls;
+        (void)hipEventRecord(e->evs[idx].a, e->stream);
+    }
+    ~Prof() { if (idx >= 0) (void)hipEventRecord(e->evs[idx].b, e->stream); }
+};
+
+void prof_collect(glc_engine* e) {
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->evs[i].a, e->evs[i].b) == hipSuccess) { e->prof_ms[e->evs[i].cls] += ms; e->prof_n[e->evs[i].cls]++; }
+    }
+    e->ev_used = 0;
+}
+
+// host f32 -> device f32
+float* upload_f32(glc_engine* e, const float* src, size_t n) {
+    float* d = (float*)dmalloc(e, n * sizeof(float), false);
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream) != hipSuccess) { set_err("H2D failed"); return nullptr; }
+    return d;
+}
+// host f32 -> device T at dst (dst preallocated), via a temporary f32 staging buffer
+bool upload_as(glc_engine* e, const float* src, size_t n, void* dst, float* staging) {
+    if (hipMemcpyAsync(staging, src, n * sizeof(float), hipMemcpyHostToDevice, e->stream) != hipSuccess) { set_err("H2D failed"); return false; }
+    const char* m = glc_launch_convert(e->stream, e->dtype, staging, dst, n);
+    if (m) { set_err(m); return false; }
+    return hipStreamSynchronize(e->stream) == hipSuccess;   // staging is reused by the caller
+}
+
+bool ensure_capacity(glc_engine* e, int B, int S, int C) {
+    const glc_model_config& c = e->cfg;
+    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 128);
+    const size_t es = esize(e->dtype);
+    if (Mpad > e->capM) {
+        void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
+        for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
+        dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
+        dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
+        e->capM = Mpad;
+        e->hidden_cap = 0;   // dump buffer is re-made lazily
+    }
+    if (B > e->capB || C > e->capC) {
+        const int nb = B > e->capB ? B : e->capB, nc = C > e->capC ? C : e->capC;
+        dfree(e, e->klen); dfree(e, e->cls_cnt); dfree(e, e->cls_pos); dfree(e, e->d_logits);
+        e->klen = (int*)dmalloc(e, (size_t)nb * sizeof(int));
+        e->cls_cnt = (int*)dmalloc(e, (size_t)nb * sizeof(int));
+        e->cls_pos = (int*)dmalloc(e, (size_t)nb * (nc > 0 ? nc : 1) * sizeof(int));
+        e->d_logits = (float*)dmalloc(e, (size_t)nb * (nc > 0 ? nc : 1) * sizeof(float));
+        if (!e->klen || !e->cls_cnt || !e->cls_pos || !e->d_logits) return false;
+        e->capB = nb; e->capC = nc;
+    }
+    if (B * S > e->capIds) {
+        dfree(e, e->d_ids); dfree(e, e->d_mask);
+        e->d_ids = (int64_t*)dmalloc(e, (size_t)B * S * sizeof(int64_t));
+        e->d_mask = (int64_t*)dmalloc(e, (size_t)B * S * sizeof(int64_t));
+        if (!e->d_ids || !e->d_mask) return false;
+        e->capIds = B * S;
+    }
+    const int hr = round_up((B * (C > 0 ? C : 1)) > B ? B * (C > 0 ? C : 1) : B, 128);
+    if (hr > e->capHeadRows) {
+        float** bufs[] = {&e->Gt, &e->Gc, &e->G1t, &e->G1c, &e->G2t, &e->G2c};
+        for (float** b : bufs) { dfree(e, *b); *b = (float*)dmalloc(e, (size_t)hr * c.hidden * sizeof(float)); if (!*b) return false; }
+        e->capHeadRows = hr;
+    }
+    if (!e->dtabs.count(Sp)) {
+        std::vector<int32_t> t(2 * Sp - 1);
+        glc_delta_table(Sp, c.pos_buckets, c.max_rel_pos, t.data());
+        int32_t* d = (int32_t*)dmalloc(e, t.size() * sizeof(int32_t), false);
+        if (!d) return false;
+        if (hipMemcpy(d, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { set_err("dtab upload failed"); return false; }
+        e->dtabs[Sp] = d;
+    }
+    return true;
+}
+
+// The launch sequence for one batch.  ids/mask are device pointers.
+bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, int C, float* d_logits) {
+    const glc_model_config& c = e->cfg;
+    const int H = c.hidden, I = c.inter, nh = c.heads;
+    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 128);
+    hipStream_t st = e->stream;
+    const int dt = e->dtype;
+    const size_t es = esize(dt);
+    const int ccap = e->capC > 0 ? e->capC : 1;
+    if (e->profile) { e->ev_used = 0; }
+
+    if (e->keep_hidden) {
+        const size_t need = (size_t)(c.layers + 1) * M * H * es;
+        if (need > e->hidden_cap) { dfree(e, e->hidden_dump); e->hidden_dump = dmalloc(e, need); if (!e->hidden_dump) return false; e->hidden_cap = need; }
+    }
+    { Prof p(e, PC_SCAN);
+      KCHK(glc_launch_scan_rows(st, ids, mask, B, S, c.class_token_index, c.embed_class_token, e->klen, e->cls_pos, e->cls_cnt, ccap), false); }
+    { Prof p(e, PC_EMBED);
+      KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
+    if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+
+    const int impl = e->attn_impl ? e->attn_impl : (dt == GLC_F32 ? 1 : 2);
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerW& w = e->layers[l];
+        GemmArgs g;
+        g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
+        g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
+        { Prof p(e, PC_QKV); KCHK(glc_launch_gemm(st, dt, EPI_QKV, g), false); }
+        AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->CTX, B, nh, Sp, H, e->P};
+        { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
+        GemmArgs o;
+        o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
+        { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm(st, dt, EPI_RESID, o), false); }
+        { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
+        GemmArgs f1;
+        f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
+        { Prof p(e, PC_FFN1); KCHK(glc_launch_gemm(st, dt, EPI_GELU, f1), false); }
+        GemmArgs f2;
+        f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
+        { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm(st, dt, EPI_RESID, f2), false); }
+        { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
+        if (e->keep_hidden)
+            HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+    }
+    if (C > 0) {
+        Prof p(e, PC_HEAD);
+        KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, e->Gc, B, Sp, H, C), false);
+        const int rt = round_up(B, 128), rc = round_up(B * C, 128);
+        GemmArgs h;
+        h.N = H; h.K = H;
+        h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.C = e->G1t; h.Mpad = rt;
+        KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
+        h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.C = e->G2t;
+        KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
+        h.A = e->Gc; h.W = e->headw[4]; h.bias = e->headw[5]; h.C = e->G1c; h.Mpad = rc;
+        KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
+        h.A = e->G1c; h.W = e->headw[6]; h.bias = e->headw[7]; h.C = e->G2c;
+        KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
+        KCHK(glc_launch_head_score(st, e->G2t, e->G2c, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
+    }
+    HIPCHK(hipGetLastError(), false);
+    e->lastB = B; e->lastS = S; e->lastSp = Sp;
+    return true;
+}
+
+bool check_shape(const glc_engine* e, int B, int S, int C) {
+    if (B <= 0 || S <= 0 || C < 0) { set_err("forward: B and S must be positive, C non-negative"); return false; }
+    if ((long long)B * round_up(S, 64) > (1ll << 30)) { set_err("forward: batch too large"); return false; }
+    (void)e;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* glc_last_error(void) { return g_err.c_str(); }
+
+int glc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* modeling_deberta_v2.py:57-69 (make_log_bucket_position) + :318 clamp; float32 arithmetic like torch */
+void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out) {
+    const int span = bucket_size > 0 ? bucket_size : max_position;
+    const int mid = bucket_size / 2;
+    const float den = (bucket_size > 0 && max_position > 0) ? logf((float)(((double)max_position - 1.0) / (double)mid)) : 1.f;
+    for (int r = -(S - 1); r <= S - 1; ++r) {
+        int bk = r;
+        if (bucket_size > 0 && max_position > 0) {
+            const int ar = r < 0 ? -r : r;
+            if (ar > mid) {
+                const float lp = ceilf(logf((float)ar / (float)mid) / den * (float)(mid - 1)) + (float)mid;
+                bk = (int)(r < 0 ? -lp : lp);
+            }
+        }
+        int v = bk + span;
+        out[r + S - 1] = v < 0 ? 0 : (v > 2 * span - 1 ? 2 * span - 1 : v);
+    }
+}
+
+glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* tensors, int n_tensors, int device, int dtype) {
+    if (!cfg || !tensors) { set_err("engine_create: null argument"); return nullptr; }
+    if (dtype != GLC_F32 && dtype != GLC_BF16 && dtype != GLC_F16) { set_err("engine_create: bad dtype"); return nullptr; }
+    if (n_tensors != glc_num_tensors(cfg->layers)) { set_err("engine_create: wrong tensor count"); return nullptr; }
+    for (int i = 0; i < n_tensors; ++i) if (!tensors[i]) { set_err("engine_create: null tensor"); return nullptr; }
+    if (cfg->head_dim != 64 || cfg->hidden != cfg->heads * 64) { set_err("engine_create: head_dim must be 64 (all DeBERTa-v3 backbones)"); return nullptr; }
+    if (cfg->hidden % 128 || cfg->inter % 128) { set_err("engine_create: hidden and intermediate sizes must be multiples of 128"); return nullptr; }
+    if (cfg->pooling != GLC_POOL_FIRST || cfg->scorer != GLC_SCORER_DOT) { set_err("engine_create: only pooling='first' and scorer='simple' are implemented"); return nullptr; }
+    int ndev = glc_device_count();
+    if (ndev <= 0) { set_err("engine_create: no HIP device visible (this engine has no CPU path)"); return nullptr; }
+    if (device < 0 || device >= ndev) { set_err("engine_create: bad device ordinal"); return nullptr; }
+    HIPCHK(hipSetDevice(device), nullptr);
+
+    glc_engine* e = new glc_engine();
+    e->cfg = *cfg; e->dtype = dtype; e->device = device;
+    const int H = cfg->hidden, I = cfg->inter, L = cfg->layers, nh = cfg->heads;
+    const int span = cfg->pos_buckets > 0 ? cfg->pos_buckets : cfg->max_rel_pos;
+    const int P = 2 * span;
+    e->P = P;
+    const size_t es = esize(dtype);
+    bool ok = false;
+    do {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { set_err("stream create failed"); break; }
+        if (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) { set_err("event create failed"); break; }
+        size_t stage_n = (size_t)cfg->vocab * H;
+        if ((size_t)I * H > stage_n) stage_n = (size_t)I * H;
+        float* staging = nullptr;
+        if (hipMalloc((void**)&staging, stage_n * sizeof(float)) != hipSuccess) { set_err("staging alloc failed"); break; }
+        auto fail = [&]() { (void)hipFree(staging); };
+
+        // embeddings (HF:518-562)
+        e->emb = dmalloc(e, (size_t)cfg->vocab * H * es, false);
+        if (!e->emb || !upload_as(e, tensors[0], (size_t)cfg->vocab * H, e->emb, staging)) { fail(); break; }
+        e->eln_g = upload_f32(e, tensors[1], H); e->eln_b = upload_f32(e, tensors[2], H);
+        if (!e->eln_g || !e->eln_b) { fail(); break; }
+
+        // R = LayerNorm(rel_embeddings) in fp32 (HF:595-599), then to T, padded to 128 rows
+        const int Ppad = round_up(P, 128);
+        float* rel_f32 = upload_f32(e, tensors[3], (size_t)P * H);
+        float* rg = upload_f32(e, tensors[4], H); float* rb = upload_f32(e, tensors[5], H);
+        float* Rf = (float*)dmalloc(e, (size_t)Ppad * H * sizeof(float));
+        void* Rt = dmalloc(e, (size_t)Ppad * H * es);
+        void* vscratch = dmalloc(e, (size_t)nh * 64 * P * es);
+        if (!rel_f32 || !rg || !rb || !Rf || !Rt || !vscratch) { fail(); break; }
+        const char* m = glc_launch_layernorm(e->stream, GLC_F32, rel_f32, Rf, rg, rb, cfg->ln_eps, P, H);
+        if (!m) m = glc_launch_convert(e->stream, dtype, Rf, Rt, (size_t)Ppad * H);
+        if (m) { set_err(m); fail(); break; }
+
+        const float inv_scale = 1.0f / sqrtf((float)cfg->head_dim * 3.0f);   // HF:237-242, scale_factor = 3
+        std::vector<float> wq((size_t)H * H), bq(H), bqkv(3 * (size_t)H);
+        e->layers.resize(L);
+        bool lok = true;
+        for (int l = 0; l < L && lok; ++l) {
+            const float* const* t = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * l;
+            LayerW& w = e->layers[l];
+            w.Wqkv = dmalloc(e, 3 * (size_t)H * H * es, false);
+            w.Wo = dmalloc(e, (size_t)H * H * es, false);
+            w.W1 = dmalloc(e, (size_t)I * H * es, false);
+            w.W2 = dmalloc(e, (size_t)H * I * es, false);
+            w.PK = dmalloc(e, (size_t)nh * P * 64 * es);
+            w.PQ = dmalloc(e, (size_t)nh * P * 64 * es);
+            if (!w.Wqkv || !w.Wo || !w.W1 || !w.W2 || !w.PK || !w.PQ) { lok = false; break; }
+            for (size_t i = 0; i < (size_t)H * H; ++i) wq[i] = t[0][i] * inv_scale;   // fold 1/sqrt(3d) into the query projection
+            for (int i = 0; i < H; ++i) { bqkv[i] = t[1][i] * inv_scale; bqkv[H + i] = t[3][i]; bqkv[2 * H + i] = t[5][i]; }
+            lok = upload_as(e, wq.data(), (size_t)H * H, w.Wqkv, staging) &&
+                  upload_as(e, t[2], (size_t)H * H, (char*)w.Wqkv + (size_t)H * H * es, staging) &&
+                  upload_as(e, t[4], (size_t)H * H, (char*)w.Wqkv + 2 * (size_t)H * H * es, staging) &&
+                  upload_as(e, t[6], (size_t)H * H, w.Wo, staging) && upload_as(e, t[10], (size_t)I * H, w.W1, staging) &&
+                  upload_as(e, t[12], (size_t)H * I, w.W2, staging);
+            if (!lok) break;
+            w.bqkv = upload_f32(e, bqkv.data(), 3 * (size_t)H);
+            w.bo = upload_f32(e, t[7], H); w.ln1g = upload_f32(e, t[8], H); w.ln1b = upload_f32(e, t[9], H);
+            w.b1 = upload_f32(e, t[11], I); w.b2 = upload_f32(e, t[13], H);
+            w.ln2g = upload_f32(e, t[14], H); w.ln2b = upload_f32(e, t[15], H);
+            if (!w.bqkv || !w.bo || !w.ln1g || !w.ln1b || !w.b1 || !w.b2 || !w.ln2g || !w.ln2b) { lok = false; break; }
+            if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // bqkv host buffer is reused
+            // position projections (HF:296-302, share_att_key): PQ = query_proj(R)/sqrt(3d), PK = key_proj(R), [nh,P,64]
+            GemmArgs g;
+            g.A = Rt; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = w.PQ; g.Kh = w.PK; g.Vt = vscratch;
+            g.Mpad = Ppad; g.N = 3 * H; g.K = H; g.Mvalid = P; g.Sp = P; g.nh = nh; g.H = H;
+            const char* gm = glc_launch_gemm(e->stream, dtype, EPI_QKV, g);
+            if (gm) { set_err(gm); lok = false; }
+        }
+        if (!lok) { fail(); break; }
+        const float* const* ht = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * L;
+        bool hok = true;
+        for (int i = 0; i < 8 && hok; ++i) { e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr; }
+        if (!hok) { fail(); break; }
+        if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err(std::string("engine_create: ") + hipGetErrorString(hipGetLastError())); fail(); break; }
+        (void)hipFree(staging);
+        dfree(e, rel_f32); dfree(e, rg); dfree(e, rb); dfree(e, Rf); dfree(e, Rt); dfree(e, vscratch);
+        ok = true;
+    } while (0);
+    if (!ok) { glc_engine_destroy(e); return nullptr; }
+    return e;
+}
+
+void glc_engine_destroy(glc_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (auto& v : e->evs) { (void)hipEventDestroy(v.a); (void)hipEventDestroy(v.b); }
+    if (e->t0) (void)hipEventDestroy(e->t0);
+    if (e->t1) (void)hipEventDestroy(e->t1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int glc_engine_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, float* logits, int c_alloc, int* c_out) {
+    if (!e || !ids || !mask || (!logits && c_alloc > 0)) { set_err("forward: null argument"); return -1; }
+    if (!check_shape(e, B, S, c_alloc)) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1);
+    if (!ensure_capacity(e, B, S, c_alloc)) return -1;
+    const size_t nb = (size_t)B * S * sizeof(int64_t);
+    HIPCHK(hipMemcpyAsync(e->d_ids, ids, nb, hipMemcpyHostToDevice, e->stream), -1);
+    HIPCHK(hipMemcpyAsync(e->d_mask, mask, nb, hipMemcpyHostToDevice, e->stream), -1);
+    if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) return -1;
+    std::vector<int> cnt(B);
+    HIPCHK(hipMemcpyAsync(cnt.data(), e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
+    if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
+    HIPCHK(hipStreamSynchronize(e->stream), -1);
+    if (e->profile) prof_collect(e);
+    int cmax = 0;
+    for (int b = 0; b < B; ++b) cmax = cnt[b] > cmax ? cnt[b] : cmax;
+    if (c_out) *c_out = cmax;
+    return 0;
+}
+
+int glc_engine_forward_device(glc_engine* e, const void* d_ids, const void* d_mask, int B, int S, int C, void* d_logits) {
+    if (!e || !d_ids || !d_mask || (!d_logits && C > 0)) { set_err("forward_device: null argument"); return -1; }
+    if (!check_shape(e, B, S, C)) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1);
+    if (!ensure_capacity(e, B, S, C)) return -1;
+    return run_forward(e, (const int64_t*)d_ids, (const int64_t*)d_mask, B, S, C, (float*)d_logits) ? 0 : -1;
+}
+
+int glc_engine_sync(glc_engine* e) {
+    if (!e) { set_err("sync: null engine"); return -1; }
+    HIPCHK(hipSetDevice(e->device), -1);
+    HIPCHK(hipStreamSynchronize(e->stream), -1);
+    if (e->profile) { std::lock_guard<std::mutex> lk(e->mu); prof_collect(e); }
+    return 0;
+}
+
+void* glc_device_malloc(glc_engine* e, size_t bytes) {
+    if (!e) { set_err("device_malloc: null engine"); return nullptr; }
+    if (hipSetDevice(e->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { set_err("device_malloc failed"); return nullptr; }
+    return p;
+}
+void glc_device_free(glc_engine* e, void* p) { if (e && p) { (void)hipSetDevice(e->device); (void)hipFree(p); } }
+int glc_memcpy_h2d(glc_engine* e, void* dst, const void* src, size_t bytes) {
+    if (!e) return -1;
+    HIPCHK(hipSetDevice(e->device), -1);
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), -1);
+    return 0;
+}
+int glc_memcpy_d2h(glc_engine* e, void* dst, const void* src, size_t bytes) {
+    if (!e) return -1;
+    HIPCHK(hipSetDevice(e->device), -1);
+    HIPCHK(hipStreamSynchronize(e->stream), -1);
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), -1);
+    return 0;
+}
+
+int glc_timer_start(glc_engine* e) {
+    if (!e) return -1;
+    HIPCHK(hipSetDevice(e->device), -1);
+    HIPCHK(hipEventRecord(e->t0, e->stream), -1);
+    return 0;
+}
+float glc_timer_stop_ms(glc_engine* e) {
+    if (!e) return -1.f;
+    HIPCHK(hipSetDevice(e->device), -1.f);
+    HIPCHK(hipEventRecord(e->t1, e->stream), -1.f);
+    HIPCHK(hipEventSynchronize(e->t1), -1.f);
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->t0, e->t1), -1.f);
+    return ms;
+}
+
+int glc_profile_enable(glc_engine* e, int on) {
+    if (!e) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->profile = on != 0;
+    e->ev_used = 0;
+    for (int i = 0; i < PC_N; ++i) { e->prof_ms[i] = 0.f; e->prof_n[i] = 0; }
+    return 0;
+}
+int glc_profile_read(glc_engine* e, const char** names, float* total_ms, int* launches, int max_n) {
+    if (!e) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int n = PC_N < max_n ? PC_N : max_n;
+    for (int i = 0; i < n; ++i) { if (names) names[i] = kProfNames[i]; if (total_ms) total_ms[i] = e->prof_ms[i]; if (launches) launches[i] = e->prof_n[i]; }
+    return n;
+}
+
+int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hidden = on != 0; return 0; }
+int glc_debug_set_attention_impl(glc_engine* e, int impl) {
+    if (!e || impl < 0 || impl > 2) { set_err("bad attention impl"); return -1; }
+    if (impl == 2 && e->dtype == GLC_F32) { set_err("MFMA attention needs 16-bit operands"); return -1; }
+    e->attn_impl = impl;
+    return 0;
+}
+int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems) {
+    if (!e || !out) { set_err("get_hidden: null"); return -1; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    const int B = e->lastB, S = e->lastS, Sp = e->lastSp, H = e->cfg.hidden;
+    if (!e->hidden_dump || B == 0 || which < 0 || which > e->cfg.layers) { set_err("get_hidden: nothing recorded"); return -1; }
+    if (out_elems < (size_t)B * S * H) { set_err("get_hidden: output too small"); return -1; }
+    HIPCHK(hipSetDevice(e->device), -1);
+    const size_t M = (size_t)B * Sp, es = esize(e->dtype);
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, M * H * sizeof(float)), -1);
+    const char* m = glc_launch_to_f32(e->stream, e->dtype, (char*)e->hidden_dump + (size_t)which * M * H * es, tmp, M * H);
+    if (m) { (void)hipFree(tmp); set_err(m); return -1; }
+    hipError_t r = hipMemcpy2DAsync(out, (size_t)S * H * sizeof(float), tmp, (size_t)Sp * H * sizeof(float), (size_t)S * H * sizeof(float), B,
+                                    hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    if (r != hipSuccess) { set_err(std::string("get_hidden: ") + hipGetErrorString(r)); return -1; }
+    return 0;
+}
+
+const glc_model_config* glc_engine_config(const glc_engine* e) { return e ? &e->cfg : nullptr; }
+int glc_engine_dtype(const glc_engine* e) { return e ? e->dtype : -1; }
+
+}  // extern "C"

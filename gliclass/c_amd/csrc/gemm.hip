@@ -1,0 +1,190 @@
+// C = A * W^T (+bias, +epilogue) on MFMA, for the encoder's dense projections
+// (modeling_deberta_v2.py:231-233 QKV, :49-53 attention output, :393-396 intermediate, :408-412 output)
+// and the GLiClass head's projectors.
+//
+// Layout: A [Mpad, K] row-major (activations), W [N, K] row-major (nn.Linear weight), both element
+// type T in {float, bf16, f16}; fp32 accumulate.  128x128 block tile, 4 waves (2x2), each wave
+// 64x64 = 4x4 MFMA 16x16 tiles.  K is consumed in stages of 128 BYTES per row (64 16-bit / 32 f32
+// elements) so the staging/LDS code is identical for every T.  Stages are double-buffered in LDS
+// (144-B padded rows -> conflict-free ds_read_b128) with the global loads of stage t+1 issued
+// before the MFMAs of stage t and written to LDS after them (issue-early / write-late).
+//
+// Output orientation: the wave computes D^T = W_tile * A_tile^T (lane = output row m, 4 regs = 4
+// consecutive columns n) so each lane stores 4 packed elements; the V third of the fused QKV GEMM
+// flips the operands (lane = n, regs = 4 consecutive m) to write V transposed, [B,nh,64,Sp], which
+// is the A-operand layout the attention kernel's P*V MFMA wants.
+#include "glc_common.h"
+#include "glc_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;          // bytes of K per row per stage
+constexpr int ROWP = ROWB + 16;    // padded LDS row stride (bytes)
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+    typedef typename Frag<T>::type frag_t;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * ROWP];
+    unsigned char* As = smem;                       // [2][BM][ROWP]
+    unsigned char* Bs = smem + 2 * BM * ROWP;       // [2][BN][ROWP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int K = p.K, N = p.N;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+
+    // staging map: thread -> 16-B chunk cc of rows (tid>>3) + 32*i
+    const int cc = tid & 7, srow = tid >> 3;
+    const T* ga = A + (size_t)(m0 + srow) * K + cc * (16 / (int)sizeof(T));
+    const T* gw = W + (size_t)(n0 + srow) * K + cc * (16 / (int)sizeof(T));
+    const size_t gstep = (size_t)32 * K;
+    u32x4 ra[4], rw[4];
+
+    const bool vmode = (EPI == EPI_QKV) && (n0 >= 2 * p.H);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const u32x4*>(ga + (size_t)i * gstep + (size_t)kt * BK);
+            rw[i] = *reinterpret_cast<const u32x4*>(gw + (size_t)i * gstep + (size_t)kt * BK);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(As + (size_t)buf * BM * ROWP + (srow + 32 * i) * ROWP + cc * 16) = ra[i];
+            *reinterpret_cast<u32x4*>(Bs + (size_t)buf * BN * ROWP + (srow + 32 * i) * ROWP + cc * 16) = rw[i];
+        }
+    };
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* as = As + (size_t)cur * BM * ROWP + (wm * 64 + r16) * ROWP + g * 16;
+        const unsigned char* bs = Bs + (size_t)cur * BN * ROWP + (wn * 64 + r16) * ROWP + g * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag_t af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const frag_t*>(as + i * 16 * ROWP + ks * 64);
+                bf[i] = *reinterpret_cast<const frag_t*>(bs + i * 16 * ROWP + ks * 64);
+            }
+            if (!vmode) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mma16(bf[j], af[i], acc[j][i]);   // D[n][m]
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16(af[i], bf[j], acc[i][j]);   // D[m][n]
+            }
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------- epilogue ----------------
+    const float* __restrict__ bias = p.bias;
+    if (!vmode) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            if (bias) { f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n); b0 = bv[0]; b1 = bv[1]; b2 = bv[2]; b3 = bv[3]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + r16;
+                float v0 = acc[j][i][0] + b0, v1 = acc[j][i][1] + b1, v2 = acc[j][i][2] + b2, v3 = acc[j][i][3] + b3;
+                if (EPI == EPI_GELU) { v0 = glc_gelu(v0); v1 = glc_gelu(v1); v2 = glc_gelu(v2); v3 = glc_gelu(v3); }
+                if (EPI == EPI_RESID) {
+                    float r0, r1, r2, r3;
+                    load4<T>(reinterpret_cast<const T*>(p.resid) + (size_t)m * N + n, r0, r1, r2, r3);
+                    v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+                }
+                if (EPI == EPI_QKV) {
+                    if (m < p.Mvalid) {
+                        const int which = n0 / p.H;                 // block-uniform: 0 = Q, 1 = K
+                        const int nn = n - which * p.H;
+                        const int hh = nn >> 6, dd = nn & 63;
+                        const int b = m / p.Sp, s = m - b * p.Sp;
+                        T* dst = reinterpret_cast<T*>(which == 0 ? p.Qh : p.Kh) + (((size_t)b * p.nh + hh) * p.Sp + s) * 64 + dd;
+                        store4<T>(dst, v0, v1, v2, v3);
+                    }
+                } else {
+                    store4<T>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n, v0, v1, v2, v3);
+                }
+            }
+        }
+    } else {
+        // V third: D[m = 4g+r][n = r16] -> Vt[b][hh][dd][s .. s+3]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + r16;
+            const float bv = bias ? bias[n] : 0.f;
+            const int nn = n - 2 * p.H;
+            const int hh = nn >> 6, dd = nn & 63;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * g;
+                if (m < p.Mvalid) {
+                    const int b = m / p.Sp, s = m - b * p.Sp;
+                    T* dst = reinterpret_cast<T*>(p.Vt) + (((size_t)b * p.nh + hh) * 64 + dd) * p.Sp + s;
+                    store4<T>(dst, acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+                }
+            }
+        }
+    }
+}
+
+template <typename T> void launch_t(hipStream_t st, int epi, const GemmArgs& a) {
+    dim3 grid(a.N / BN, a.Mpad / BM), block(256);
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, a); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU>), grid, block, 0, st, a); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID>), grid, block, 0, st, a); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_QKV>), grid, block, 0, st, a); break;
+    }
+}
+
+}  // namespace
+
+// Host-side shape contract (checked here so a bad shape can never reach the kernel):
+//   Mpad % 128 == 0 and every [Mpad, *] buffer is allocated with Mpad rows; N % 128 == 0;
+//   K % (128 / sizeof(T)) == 0; for EPI_QKV additionally H % 128 == 0, Sp % 4 == 0.
+const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
+    const int esz = dtype == GLC_DT_F32 ? 4 : 2;
+    if (a.Mpad <= 0 || a.Mpad % BM) return "gemm: Mpad must be a positive multiple of 128";
+    if (a.N <= 0 || a.N % BN) return "gemm: N must be a multiple of 128";
+    if (a.K <= 0 || a.K % (ROWB / esz)) return "gemm: K must be a multiple of 128 bytes";
+    if (!a.A || !a.W) return "gemm: null operand";
+    if (epi == EPI_QKV) {
+        if (a.H % 128 || a.N != 3 * a.H || a.Sp % 4 || !a.Qh || !a.Kh || !a.Vt || a.nh * 64 != a.H) return "gemm: bad QKV epilogue shape";
+    } else if (!a.C) return "gemm: null output";
+    if (epi == EPI_RESID && !a.resid) return "gemm: null residual";
+    switch (dtype) {
+        case GLC_DT_F32: launch_t<float>(st, epi, a); break;
+        case GLC_DT_BF16: launch_t<bf16_t>(st, epi, a); break;
+        case GLC_DT_F16: launch_t<f16_t>(st, epi, a); break;
+        default: return "gemm: bad dtype";
+    }
+    return nullptr;
+}

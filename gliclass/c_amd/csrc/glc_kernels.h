@@ -1,0 +1,63 @@
+// Internal launcher interface between engine.hip and the kernel translation units.
+// Every launcher validates the shapes its kernel assumes and returns an error string
+// (nullptr = launched) instead of launching on a bad shape.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { GLC_DT_F32 = 0, GLC_DT_BF16 = 1, GLC_DT_F16 = 2 };  // == GLC_F32/BF16/F16 of gliclass_hip.h
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3 };
+
+struct GemmArgs {
+    const void* A = nullptr;      // [Mpad, K]  T
+    const void* W = nullptr;      // [N, K]     T
+    const float* bias = nullptr;  // [N] or null
+    void* C = nullptr;            // [Mpad, N]  T   (BIAS / GELU / RESID)
+    const void* resid = nullptr;  // [Mpad, N]  T   (RESID)
+    void* Qh = nullptr;           // [B, nh, Sp, 64] T (QKV)
+    void* Kh = nullptr;           // [B, nh, Sp, 64] T
+    void* Vt = nullptr;           // [B, nh, 64, Sp] T
+    int Mpad = 0, N = 0, K = 0;
+    int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
+};
+const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);
+
+// Row LayerNorm: Y[m,:] = LN(X[m,:]) * gamma + beta, rows [0, M).  X, Y element type T.
+const char* glc_launch_layernorm(hipStream_t st, int dtype, const void* X, void* Y, const float* gamma,
+                                 const float* beta, float eps, int M, int H);
+
+// Embedding gather + LayerNorm + mask (modeling_deberta_v2.py:533,550,552-559) on the padded
+// [B, Sp] grid (positions s >= S behave as padding); also writes the additive key bias
+// kbias[b*Sp+s] = mask ? 0 : -1e30.
+const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, const int64_t* mask, const void* table,
+                             const float* gamma, const float* beta, float eps, void* X, float* kbias,
+                             int B, int S, int Sp, int H, int vocab, int pad_id);
+
+// Per batch row: klen[b] = 1 + last valid key (0 if none); ordered positions of class tokens
+// cls_pos[b*c_cap + j] (-1 beyond the row's count) and cls_cnt[b].
+const char* glc_launch_scan_rows(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int S,
+                                 int class_token, int embed_class_token, int* klen, int* cls_pos, int* cls_cnt, int c_cap);
+
+struct AttnArgs {
+    const void* Qh; const void* Kh; const void* Vt;   // as written by EPI_QKV (Q pre-scaled by 1/sqrt(3d))
+    const void* PK; const void* PQ;                   // [nh, P, 64] T: key_proj(rel), query_proj(rel)/sqrt(3d)
+    const int32_t* dtab;                              // [2*Sp-1] clamp(bucket(q-k)+span)
+    const float* kbias;                               // [B, Sp]
+    const int* klen;                                  // [B]
+    void* CTX;                                        // [B*Sp, H] T
+    int B, nh, Sp, H, P;
+};
+// impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
+const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
+
+// Head: gather pooled rows -> Gt [B,H] and class-token rows -> Gc [B*C,H], both fp32.
+const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap,
+                                   float* Gt, float* Gc, int B, int Sp, int H, int C);
+// logits[b*C+j] = <Tt[b], Cc[b*C+j]> (* logit_scale when normalised)
+const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* Cc, float* logits, int B, int C, int H,
+                                  int normalize, float logit_scale);
+
+// dtype conversion fp32 -> T (weights upload), n elements
+const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);
+// T [rows, H] -> fp32 (debug dumps)
+const char* glc_launch_to_f32(hipStream_t st, int dtype, const void* src, float* dst, size_t n);

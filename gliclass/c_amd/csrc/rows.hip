@@ -1,0 +1,243 @@
+// Row-wise (HBM-bound) kernels: embedding gather + LayerNorm + mask, LayerNorm, the per-row input
+// scan, head gather / dot-product scorer and dtype conversion.  One wave per row, 16-byte vector
+// accesses, fp32 statistics with wavefront shuffles (no LDS).
+#include "glc_common.h"
+#include "glc_kernels.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // chunks of 16 B per lane: H <= 64*MAXC*VEC (H <= 2048 for 16-bit, 1024 for f32)
+
+template <typename T> struct RowVec { static constexpr int VEC = 16 / (int)sizeof(T); };
+
+// LayerNorm of one row held in registers by one wave. torch.nn.LayerNorm semantics (biased var).
+template <typename T, bool MASKED>
+__device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float eps, int H, float mk, int lane) {
+    constexpr int VEC = RowVec<T>::VEC;
+    typedef __attribute__((ext_vector_type(VEC))) T vecT;
+    const int nch = H / VEC;
+    float v[MAXC][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            vecT t = *reinterpret_cast<const vecT*>(x + (size_t)ch * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (lane + 64 * c < nch) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[c][e] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            vecT o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float r = (v[c][e] - mean) * rstd * gamma[ch * VEC + e] + beta[ch * VEC + e];
+                if (MASKED) r *= mk;
+                o[e] = (T)r;
+            }
+            *reinterpret_cast<vecT*>(y + (size_t)ch * VEC) = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int M, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    ln_row_wave<T, false>(X + (size_t)row * H, Y + (size_t)row * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+                                                    const T* __restrict__ table, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps, T* __restrict__ X,
+                                                    float* __restrict__ kbias, int B, int S, int Sp, int H, int vocab, int pad_id) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row in the padded [B, Sp] grid
+    if (row >= B * Sp) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / Sp, s = row - b * Sp;
+    long long id = pad_id;
+    float mk = 0.f;
+    if (s < S) {
+        id = ids[(size_t)b * S + s];
+        mk = mask[(size_t)b * S + s] != 0 ? 1.f : 0.f;
+        if (id < 0 || id >= vocab) id = pad_id;
+    }
+    if (lane == 0) kbias[row] = mk != 0.f ? 0.f : GLC_NEG_BIG;
+    ln_row_wave<T, true>(table + (size_t)id * H, X + (size_t)row * H, gamma, beta, eps, H, mk, lane);
+}
+
+// one block per batch row; ordered compaction of class-token positions by a block-wide scan
+__global__ __launch_bounds__(256) void scan_rows_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int S,
+                                                        int class_token, int embed_class_token, int* __restrict__ klen,
+                                                        int* __restrict__ cls_pos, int* __restrict__ cls_cnt, int c_cap) {
+    __shared__ int cnt[256];
+    __shared__ int last[256];
+    __shared__ int tot;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int per = (S + 255) / 256;
+    const int lo = t * per, hi = min(S, lo + per);
+    int c = 0, lv = 0;
+    for (int s = lo; s < hi; ++s) {
+        c += ids[(size_t)b * S + s] == class_token;
+        if (mask[(size_t)b * S + s] != 0) lv = s + 1;
+    }
+    cnt[t] = c;
+    last[t] = lv;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0, mx = 0;
+        for (int i = 0; i < 256; ++i) { const int v = cnt[i]; cnt[i] = run; run += v; mx = max(mx, last[i]); }
+        cls_cnt[b] = run;
+        klen[b] = mx;
+        tot = run;
+    }
+    __syncthreads();
+    int j = cnt[t];
+    for (int s = lo; s < hi; ++s)
+        if (ids[(size_t)b * S + s] == class_token) {
+            if (j < c_cap) cls_pos[(size_t)b * c_cap + j] = embed_class_token ? s : min(s + 1, S - 1);
+            ++j;
+        }
+    // slots beyond this row's count
+    for (int k = tot + t; k < c_cap; k += 256) cls_pos[(size_t)b * c_cap + k] = -1;
+}
+
+// Gt rows [0,B): pooled = hidden[b, 0, :] ("first" pooling); Gc rows b*C + j: class token j (zeros if absent)
+template <typename T>
+__global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
+                                                          float* __restrict__ Gt, float* __restrict__ Gc, int B, int Sp, int H, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * (1 + C)) return;
+    const int lane = threadIdx.x & 63;
+    long long src = -1;
+    float* dst;
+    if (row < B) { src = (long long)row * Sp; dst = Gt + (size_t)row * H; }
+    else {
+        const int r = row - B, b = r / C, j = r - b * C;
+        const int pos = j < c_cap ? cls_pos[(size_t)b * c_cap + j] : -1;
+        if (pos >= 0) src = (long long)b * Sp + pos;
+        dst = Gc + (size_t)r * H;
+    }
+    for (int i = lane; i < H; i += 64) dst[i] = src >= 0 ? (float)X[(size_t)src * H + i] : 0.f;
+}
+
+// logits[b*C + j] = <Tt[b], Cc[b*C+j]>   (gliclass scorer 'simple': einsum('BD,BCD->BC'))
+__global__ __launch_bounds__(256) void head_score_kernel(const float* __restrict__ Tt, const float* __restrict__ Cc,
+                                                         float* __restrict__ logits, int B, int C, int H, int normalize,
+                                                         float logit_scale) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= B * C) return;
+    const int lane = threadIdx.x & 63;
+    const int b = idx / C;
+    const float* t = Tt + (size_t)b * H;
+    const float* c = Cc + (size_t)idx * H;
+    float dot = 0.f, nt = 0.f, nc = 0.f;
+    for (int i = lane; i < H; i += 64) { const float a = t[i], d = c[i]; dot += a * d; nt += a * a; nc += d * d; }
+    dot = wave_sum(dot);
+    if (normalize) {
+        nt = wave_sum(nt); nc = wave_sum(nc);
+        dot = dot / ((sqrtf(nt) + 1e-8f) * (sqrtf(nc) + 1e-8f)) * logit_scale;
+    }
+    if (lane == 0) logits[idx] = dot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (T)src[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
+template <typename T> bool h_ok(int H) { return H > 0 && H % RowVec<T>::VEC == 0 && H / RowVec<T>::VEC <= 64 * MAXC; }
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                   \
+    switch (dtype) {                                              \
+        case GLC_DT_F32: { typedef float T; CALL; } break;        \
+        case GLC_DT_BF16: { typedef bf16_t T; CALL; } break;      \
+        case GLC_DT_F16: { typedef f16_t T; CALL; } break;        \
+        default: return "bad dtype";                              \
+    }
+
+const char* glc_launch_layernorm(hipStream_t st, int dtype, const void* X, void* Y, const float* gamma, const float* beta,
+                                 float eps, int M, int H) {
+    if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm: bad args";
+    DISPATCH_T(dtype, {
+        if (!h_ok<T>(H)) return "layernorm: unsupported hidden size";
+        hipLaunchKernelGGL(layernorm_kernel<T>, dim3((M + 3) / 4), dim3(256), 0, st, (const T*)X, (T*)Y, gamma, beta, eps, M, H);
+    });
+    return nullptr;
+}
+
+const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, const int64_t* mask, const void* table,
+                             const float* gamma, const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp,
+                             int H, int vocab, int pad_id) {
+    if (B <= 0 || S <= 0 || Sp < S || !ids || !mask || !table || !X || !kbias) return "embed: bad args";
+    if (pad_id < 0 || pad_id >= vocab) return "embed: pad id outside vocab";
+    DISPATCH_T(dtype, {
+        if (!h_ok<T>(H)) return "embed: unsupported hidden size";
+        hipLaunchKernelGGL(embed_kernel<T>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, (const T*)table, gamma, beta, eps,
+                           (T*)X, kbias, B, S, Sp, H, vocab, pad_id);
+    });
+    return nullptr;
+}
+
+const char* glc_launch_scan_rows(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int S, int class_token,
+                                 int embed_class_token, int* klen, int* cls_pos, int* cls_cnt, int c_cap) {
+    if (B <= 0 || S <= 0 || c_cap <= 0 || !ids || !mask || !klen || !cls_pos || !cls_cnt) return "scan_rows: bad args";
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, class_token, embed_class_token, klen, cls_pos,
+                       cls_cnt, c_cap);
+    return nullptr;
+}
+
+const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap, float* Gt, float* Gc,
+                                   int B, int Sp, int H, int C) {
+    if (B <= 0 || C < 0 || !X || !cls_pos || !Gt || !Gc) return "head_gather: bad args";
+    const int rows = B * (1 + C);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL(head_gather_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, Gt, Gc, B, Sp, H, C);
+    });
+    return nullptr;
+}
+
+const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* Cc, float* logits, int B, int C, int H,
+                                  int normalize, float logit_scale) {
+    if (B <= 0 || C <= 0 || !Tt || !Cc || !logits) return "head_score: bad args";
+    hipLaunchKernelGGL(head_score_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, Tt, Cc, logits, B, C, H, normalize, logit_scale);
+    return nullptr;
+}
+
+const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n) {
+    if (!src || !dst) return "convert: null";
+    if (n == 0) return nullptr;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    DISPATCH_T(dtype, { hipLaunchKernelGGL(convert_kernel<T>, dim3(grid), dim3(256), 0, st, src, (T*)dst, n); });
+    return nullptr;
+}
+
+const char* glc_launch_to_f32(hipStream_t st, int dtype, const void* src, float* dst, size_t n) {
+    if (!src || !dst) return "to_f32: null";
+    if (n == 0) return nullptr;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    DISPATCH_T(dtype, { hipLaunchKernelGGL(to_f32_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, dst, n); });
+    return nullptr;
+}

@@ -1,0 +1,178 @@
+/*
+ * Drop-in for /root/reference/src/model.c on MI355X: same seven functions (include/model.h), but
+ * the session is a set of gfx950 engines (one per GPU) and run_inference() is one hand-written HIP
+ * forward instead of g_ort->Run().  Host side is pure C; all device work goes through the C-ABI of
+ * include/gliclass_hip.h.  There is no CPU execution path: create_ort_session() fails if no GPU
+ * is visible.
+ *
+ * Runtime settings (the reference has only compile-time #defines, /root/reference/include/configs.h):
+ *   GLICLASS_DEVICES = "0,1,.." GPUs a session spans (default "0"; "all" = every visible GPU)
+ *   GLICLASS_DTYPE   = f16 | bf16 | f32   operand type of the GEMM/attention kernels (default f16)
+ */
+#include "model.h"
+
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "glc_host_internal.h"
+#include "glc_weights.h"
+
+__attribute__((weak)) const OrtApi* g_ort = NULL;
+
+/* /root/reference/src/model.c:17-29 — ragged int** -> contiguous int64 (caller frees) */
+int64_t* flatten_int_array(int** data, size_t rows, size_t cols) {
+    int64_t* flat = (int64_t*)malloc((rows && cols ? rows * cols : 1) * sizeof(int64_t));
+    if (!flat) { fprintf(stderr, "Error: Memory allocation for flat_data failed\n"); return NULL; }
+    for (size_t r = 0; r < rows; ++r) {
+        const int* src = data[r];
+        int64_t* dst = flat + r * cols;
+        for (size_t c = 0; c < cols; ++c) dst[c] = (int64_t)src[c];
+    }
+    return flat;
+}
+
+/* /root/reference/src/model.c:39-71 — wrap as an INT64 [rows, cols] tensor (no copy, no ownership) */
+OrtValue* create_tensor(int64_t* data, size_t rows, size_t cols) {
+    if (!g_ort) { fprintf(stderr, "Error: initialize_ort_api() was not called\n"); return NULL; }
+    OrtMemoryInfo* mi = NULL;
+    OrtStatus* st = g_ort->CreateCpuMemoryInfo(OrtArenaAllocator, OrtMemTypeDefault, &mi);
+    if (st) { fprintf(stderr, "Error: Failed to create MemoryInfo: %s\n", g_ort->GetErrorMessage(st)); g_ort->ReleaseStatus(st); return NULL; }
+    int64_t dims[2] = {(int64_t)rows, (int64_t)cols};
+    OrtValue* t = NULL;
+    st = g_ort->CreateTensorWithDataAsOrtValue(mi, data, rows * cols * sizeof(int64_t), dims, 2, ONNX_TENSOR_ELEMENT_DATA_TYPE_INT64, &t);
+    g_ort->ReleaseMemoryInfo(mi);
+    if (st) { fprintf(stderr, "Error: Failed to create tensor: %s\n", g_ort->GetErrorMessage(st)); g_ort->ReleaseStatus(st); return NULL; }
+    return t;
+}
+
+/* /root/reference/src/model.c:81-108.  Unlike the reference (which leaks the flattened buffers on the
+ * success path), the tensors made here own their buffer: ReleaseValue frees it. */
+int prepare_input_tensors(TokenizedInputs* tok, OrtValue** ids_t, OrtValue** mask_t) {
+    if (!tok || !ids_t || !mask_t) return -1;
+    int64_t* ids = flatten_int_array(tok->input_ids, tok->batch_size, tok->seq_length);
+    if (!ids) return -1;
+    *ids_t = create_tensor(ids, tok->batch_size, tok->seq_length);
+    if (!*ids_t) { free(ids); return -1; }
+    (*ids_t)->owns_data = 1;
+    int64_t* mask = flatten_int_array(tok->attention_mask, tok->batch_size, tok->seq_length);
+    if (!mask) { g_ort->ReleaseValue(*ids_t); *ids_t = NULL; return -1; }
+    *mask_t = create_tensor(mask, tok->batch_size, tok->seq_length);
+    if (!*mask_t) { free(mask); g_ort->ReleaseValue(*ids_t); *ids_t = NULL; return -1; }
+    (*mask_t)->owns_data = 1;
+    return 0;
+}
+
+void initialize_ort_api() { g_ort = OrtGetApiBase()->GetApi(ORT_API_VERSION); } /* /root/reference/src/model.c:303-305 */
+
+OrtEnv* initialize_ort_environment() { /* /root/reference/src/model.c:288-298 */
+    if (!g_ort) { fprintf(stderr, "Error: initialize_ort_api() was not called\n"); return NULL; }
+    OrtEnv* env = NULL;
+    OrtStatus* st = g_ort->CreateEnv(ORT_LOGGING_LEVEL_WARNING, "GLiClass", &env);
+    if (st) { fprintf(stderr, "Error: Failed to create env for ONNX Runtime: %s\n", g_ort->GetErrorMessage(st)); g_ort->ReleaseStatus(st); return NULL; }
+    return env;
+}
+
+static int parse_dtype(void) {
+    const char* s = getenv("GLICLASS_DTYPE");
+    if (!s || !*s || !strcmp(s, "f16") || !strcmp(s, "fp16")) return GLC_F16;
+    if (!strcmp(s, "bf16")) return GLC_BF16;
+    if (!strcmp(s, "f32") || !strcmp(s, "fp32")) return GLC_F32;
+    fprintf(stderr, "Warning: unknown GLICLASS_DTYPE '%s', using f16\n", s);
+    return GLC_F16;
+}
+
+/* /root/reference/src/model.c:217-281.  num_threads only mattered to ONNXRuntime's CPU thread pools. */
+OrtSession* create_ort_session(OrtEnv* env, const char* model_path, int num_threads) {
+    (void)num_threads;
+    if (!env || !model_path) { fprintf(stderr, "Error: Failed to create session: null argument\n"); return NULL; }
+    const int ndev = glc_device_count();
+    if (ndev <= 0) { fprintf(stderr, "Error: Failed to create session: no MI355X/HIP device visible (no CPU path exists)\n"); return NULL; }
+    int devs[GLC_MAX_DEVICES], nd = 0;
+    const char* ds = getenv("GLICLASS_DEVICES");
+    if (!ds || !*ds) devs[nd++] = 0;
+    else if (!strcmp(ds, "all")) { for (int i = 0; i < ndev && nd < GLC_MAX_DEVICES; ++i) devs[nd++] = i; }
+    else {
+        const char* p = ds;
+        while (*p && nd < GLC_MAX_DEVICES) {
+            char* end;
+            long v = strtol(p, &end, 10);
+            if (end == p || v < 0 || v >= ndev) { fprintf(stderr, "Error: Failed to create session: bad GLICLASS_DEVICES '%s' (%d visible)\n", ds, ndev); return NULL; }
+            devs[nd++] = (int)v;
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') { fprintf(stderr, "Error: Failed to create session: bad GLICLASS_DEVICES '%s'\n", ds); return NULL; }
+        }
+    }
+    glc_weights w;
+    if (glc_weights_load(model_path, &w) != 0) { fprintf(stderr, "Error: Failed to create session: cannot load '%s'\n", model_path); return NULL; }
+    OrtSession* s = (OrtSession*)calloc(1, sizeof(OrtSession));
+    if (!s) { glc_weights_free(&w); return NULL; }
+    s->cfg = w.cfg;
+    const int dtype = parse_dtype();
+    for (int i = 0; i < nd; ++i) {
+        glc_engine* e = glc_engine_create(&w.cfg, w.tensors, w.n_tensors, devs[i], dtype);
+        if (!e) {
+            fprintf(stderr, "Error: Failed to create session: %s\n", glc_last_error());
+            for (int k = 0; k < s->n_engines; ++k) glc_engine_destroy(s->engines[k]);
+            free(s);
+            glc_weights_free(&w);
+            return NULL;
+        }
+        s->engines[s->n_engines] = e;
+        s->devices[s->n_engines++] = devs[i];
+    }
+    glc_weights_free(&w);
+    printf("\tUsing MI355X HIP engine on %d GPU(s).\n", s->n_engines);
+    return s;
+}
+
+static OrtValue* run_on_engine(OrtSession* s, glc_engine* e, OrtValue* ids_t, OrtValue* mask_t) {
+    if (!ids_t || !mask_t || ids_t->type != ONNX_TENSOR_ELEMENT_DATA_TYPE_INT64 || mask_t->type != ONNX_TENSOR_ELEMENT_DATA_TYPE_INT64 ||
+        ids_t->ndim != 2 || mask_t->ndim != 2 || ids_t->dims[0] != mask_t->dims[0] || ids_t->dims[1] != mask_t->dims[1]) {
+        fprintf(stderr, "Error during inference: input_ids / attention_mask must be INT64 [batch, seq] tensors of equal shape\n");
+        return NULL;
+    }
+    const int B = (int)ids_t->dims[0], S = (int)ids_t->dims[1];
+    const int64_t* ids = (const int64_t*)ids_t->data;
+    /* the graph's dynamic output width: max number of <<LABEL>> tokens in a row */
+    int C = 0;
+    for (int b = 0; b < B; ++b) {
+        int c = 0;
+        for (int t = 0; t < S; ++t) c += ids[(size_t)b * S + t] == s->cfg.class_token_index;
+        if (c > C) C = c;
+    }
+    float* logits = (float*)calloc((size_t)B * (C ? C : 1), sizeof(float));
+    if (!logits) { fprintf(stderr, "Error during inference: out of memory\n"); return NULL; }
+    int c_out = 0;
+    if (glc_engine_forward(e, ids, (const int64_t*)mask_t->data, B, S, logits, C, &c_out) != 0) {
+        fprintf(stderr, "Error during inference: %s\n", glc_last_error());
+        free(logits);
+        return NULL;
+    }
+    int64_t dims[2] = {B, C};
+    OrtValue* out = glc_value_new(ONNX_TENSOR_ELEMENT_DATA_TYPE_FLOAT, dims, 2, logits, 1);
+    if (!out) free(logits);
+    return out; /* caller releases with g_ort->ReleaseValue (/root/reference/src/model.c:204-206) */
+}
+
+/* /root/reference/src/model.c:122-207.  Safe to call concurrently on one session
+ * (/root/reference/main.c:141-149): calls are dealt round-robin to the session's GPUs and each engine
+ * serialises internally. */
+OrtValue* run_inference(OrtSession* session, OrtValue* ids_t, OrtValue* mask_t) {
+    if (!session || session->n_engines <= 0) { fprintf(stderr, "Error during inference: invalid session\n"); return NULL; }
+    unsigned k = __atomic_fetch_add(&session->next, 1u, __ATOMIC_RELAXED) % (unsigned)session->n_engines;
+    return run_on_engine(session, session->engines[k], ids_t, mask_t);
+}
+
+void parallel_inference(OrtSession* session, OrtValue** ids_ts, OrtValue** mask_ts, size_t num_batches, OrtValue** outs) {
+    if (!session || session->n_engines <= 0) { for (size_t i = 0; i < num_batches; ++i) outs[i] = NULL; return; }
+    const int G = session->n_engines;
+#pragma omp parallel num_threads(G)
+    {
+        const int g = omp_get_thread_num();
+        for (size_t i = (size_t)g; i < num_batches; i += (size_t)G) outs[i] = run_on_engine(session, session->engines[g], ids_ts[i], mask_ts[i]);
+    }
+}
+
+int glc_session_num_devices(const OrtSession* session) { return session ? session->n_engines : 0; }

@@ -111,7 +111,7 @@ def write_blob(path: str, cfg: GLiClassConfig, tensors: Dict[str, np.ndarray]) -
         shape = list(a.shape) + [0] * (4 - a.ndim)
         nm = n.encode("utf-8")
         assert len(nm) < 96
-        recs.append(nm + b"\x00" * (96 - len(nm)) + struct.pack("<II4QQQ", 0, a.ndim, *shape, off, a.nbytes))
+        recs.append(nm + b"\x00" * (96 - len(nm)) + struct.pack("<II4QQQ", 0, a.ndim, *shape, off, a.nbytes) + b"\x00" * 8)
         assert len(recs[-1]) == TENSOR_REC_BYTES
         offs.append(off)
         off = (off + a.nbytes + 63) // 64 * 64

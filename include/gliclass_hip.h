@@ -1,0 +1,113 @@
+/*
+ * gliclass_hip.h — C-ABI of the MI355X (gfx950) GLiClass forward engine ("the HIP shim").
+ *
+ * This is the boundary the pure-C host code (gliclass/c_amd/host/model.c — the drop-in for
+ * /root/reference/src/model.c) binds to.  Plain pointers and sizes only; no C++/torch types.
+ * Each entry point names the reference interface it stands in for:
+ *
+ *   glc_engine_create      <- g_ort->CreateSession(env, model_path, opts, &session)
+ *                             /root/reference/src/model.c:269 (graph load + optimise, once)
+ *   glc_engine_forward     <- g_ort->Run(session, ..., input_ids, attention_mask -> logits)
+ *                             /root/reference/src/model.c:173-182  (the whole hot path)
+ *   glc_engine_destroy     <- g_ort->ReleaseSession          /root/reference/main.c:186
+ *   glc_delta_table        <- make_log_bucket_position in the exported graph
+ *   glc_last_error         <- g_ort->GetErrorMessage(status) /root/reference/src/model.c:194
+ *
+ * Error convention (mirrors /root/reference/src/model.c): pointer-returning calls return NULL,
+ * int-returning calls return non-zero; the message is available from glc_last_error().
+ */
+#ifndef GLICLASS_HIP_H
+#define GLICLASS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* arithmetic type of the GEMM/attention operands (accumulation, LayerNorm statistics, softmax and
+ * the scorer head are always fp32) */
+enum { GLC_F32 = 0, GLC_BF16 = 1, GLC_F16 = 2 };
+enum { GLC_POOL_FIRST = 0, GLC_POOL_AVG = 1 };
+enum { GLC_SCORER_DOT = 0 };
+
+/* Same int/float slots, same order, as the .glcw blob header (gliclass/c_amd/weights.py). */
+typedef struct glc_model_config {
+    int32_t vocab, hidden, layers, heads, head_dim, inter, pos_buckets, max_rel_pos;
+    int32_t pad_id, cls_id, sep_id, class_token_index, text_token_index;
+    int32_t pooling, scorer, embed_class_token, normalize_features;
+    float ln_eps, logit_scale;
+} glc_model_config;
+
+/* Tensor order expected in `tensors[]` (all fp32, row-major, nn.Linear weights are [out,in]):
+ *   0 embeddings.word_embeddings.weight [vocab,H]      1,2 embeddings.LayerNorm.{weight,bias}
+ *   3 encoder.rel_embeddings.weight [2*span,H]         4,5 encoder.LayerNorm.{weight,bias}
+ *   6+16*l .. : layer l: q.w q.b k.w k.b v.w v.b  attn.out.w attn.out.b attn.LN.w attn.LN.b
+ *                        inter.w inter.b  out.w out.b out.LN.w out.LN.b
+ *   then text_projector.linear_1.{w,b} linear_2.{w,b}, classes_projector.linear_1.{w,b} linear_2.{w,b} */
+#define GLC_TENSORS_FIXED 6
+#define GLC_TENSORS_PER_LAYER 16
+#define GLC_TENSORS_HEAD 8
+static inline int glc_num_tensors(int layers) { return GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * layers + GLC_TENSORS_HEAD; }
+
+typedef struct glc_engine glc_engine;
+
+int glc_device_count(void);
+const char* glc_last_error(void);
+
+/* Uploads + converts weights, precomputes LayerNorm(rel_embeddings) and the per-layer position
+ * projections (batch independent).  `device` = HIP ordinal.  Host tensors may be freed afterwards. */
+glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* tensors, int n_tensors,
+                              int device, int dtype);
+void glc_engine_destroy(glc_engine* e);
+
+/* Host-buffer forward: ids/mask int64 [B,S] row-major (what create_tensor() wraps,
+ * /root/reference/src/model.c:39-71).  Writes logits[b*c_alloc + j], j < *c_out, where
+ * *c_out = max over rows of the number of class tokens (the ONNX graph's dynamic C).
+ * Blocking; thread-safe per engine (internally serialised, cf. /root/reference/main.c:143-146). */
+int glc_engine_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S,
+                       float* logits, int c_alloc, int* c_out);
+
+/* Device-resident forward (bench / pipelined callers): d_ids, d_mask int64 [B,S] and d_logits
+ * f32 [B,C] are device pointers on this engine's device; C = number of class-token slots to score.
+ * Enqueues on the engine stream and returns; call glc_engine_sync() to wait. */
+int glc_engine_forward_device(glc_engine* e, const void* d_ids, const void* d_mask, int B, int S, int C,
+                              void* d_logits);
+int glc_engine_sync(glc_engine* e);
+
+/* Device memory helpers so a host language can stage buffers without linking HIP itself. */
+void* glc_device_malloc(glc_engine* e, size_t bytes);
+void glc_device_free(glc_engine* e, void* p);
+int glc_memcpy_h2d(glc_engine* e, void* dst, const void* src, size_t bytes);
+int glc_memcpy_d2h(glc_engine* e, void* dst, const void* src, size_t bytes);
+
+/* HIP-event timing on the engine stream (the stream every kernel is launched on). */
+int glc_timer_start(glc_engine* e);
+float glc_timer_stop_ms(glc_engine* e); /* records, synchronises, returns elapsed ms (<0 on error) */
+
+/* Per-kernel-class profile: when enabled every launch is bracketed by HIP events.
+ * glc_profile_read returns the number of classes and fills name/total_ms/launch counts. */
+#define GLC_PROFILE_MAX 16
+int glc_profile_enable(glc_engine* e, int on);
+int glc_profile_read(glc_engine* e, const char** names, float* total_ms, int* launches, int max_n);
+
+/* Diagnostics for parity tests: copy a hidden state of the LAST forward to host as fp32
+ * [B,S,H]; which = 0 embeddings output, l+1 = output of layer l.  Only valid after
+ * glc_debug_keep_hidden(e,1) was set before the forward. */
+int glc_debug_keep_hidden(glc_engine* e, int on);
+int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems);
+/* Force the reference (non-MFMA) attention kernel: 0 auto, 1 simple, 2 mfma. */
+int glc_debug_set_attention_impl(glc_engine* e, int impl);
+
+/* clamp(bucket(q-k)+span, 0, 2span-1) for q-k in [-(S-1), S-1] at out[q-k+S-1] (float32 math as
+ * torch).  Pure host function (no GPU needed). */
+void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out);
+
+const glc_model_config* glc_engine_config(const glc_engine* e);
+int glc_engine_dtype(const glc_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLICLASS_HIP_H */

@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sequences/s of the GLiClass forward (the work behind run_inference(),
+/root/reference/src/model.c:122-207) at BASELINE.json's config c3 — gliclass-base shape, batch 64,
+seq 1024, 8 labels — one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f16|bf16|f32] [--config base]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward over one batch whose token ids / mask are already resident in HBM
+(glc_engine_forward_device).  Every rank owns a full batch (weak scaling; sequences are
+independent, so there is no data-path collective — SURVEY.md §8e); value = N*B*K / max-over-ranks time.
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
+(the C oracle — a port, not ONNXRuntime — on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def kernel_flops(cfg, B, S):
+    """Algorithmic FLOPs of ONE launch of each kernel class (SURVEY.md §8d terms)."""
+    H, I, P = cfg.hidden, cfg.inter, 2 * cfg.att_span
+    M = B * S
+    return {
+        "gemm_qkv": 2.0 * M * H * 3 * H,
+        "attention": B * S * (4.0 * S * H + 4.0 * P * H),
+        "gemm_attn_out": 2.0 * M * H * H,
+        "gemm_ffn1_gelu": 2.0 * M * H * I,
+        "gemm_ffn2": 2.0 * M * I * H,
+    }
+
+
+def time_steps(step_fn, sync_fn, barrier_fn, max_fn, steps, warmup):
+    """The timing contract: W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on
+    both sides; returns the max over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    t1 = time.perf_counter()
+    return max_fn(t1 - t0)
+
+
+def shard_rows(n_rows, world, rank):
+    """Contiguous batch split used when ONE batch is partitioned (strong mode / host sharding):
+    rank g gets rows [g*n/G, (g+1)*n/G)."""
+    lo = n_rows * rank // world
+    hi = n_rows * (rank + 1) // world
+    return lo, hi
+
+
+def cpu_baseline(cfg, wptrs, n_t, S, C_labels, seqs):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    from gliclass.c_amd import synth
+    ids, mask, _ = synth.make_inputs(cfg, seqs, S, C_labels, seed=1234)
+    lib = oracle_c.lib()
+    logits = np.zeros((seqs, C_labels), np.float32)
+    c_out = C.c_int(0)
+    cc = oracle_c._cfg(cfg)
+    ptrs = C.cast(wptrs, C.POINTER(C.c_void_p))
+    t0 = time.perf_counter()
+    rc = lib.glo_forward(C.byref(cc), ptrs, ids.ctypes.data, mask.ctypes.data, seqs, S, logits.ctypes.data, C_labels,
+                         C.byref(c_out), None, None)
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError("oracle failed")
+    return dict(value=seqs / dt, unit="sequences/s", cores=int(lib.glo_num_threads()), kind="port",
+                sample=f"{seqs} sequence(s) of the same workload (S={S}, {C_labels} labels), fp32 C/OpenMP oracle "
+                       f"(CPU restatement, not ONNXRuntime), {dt:.1f} s"), logits, ids, mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default=os.environ.get("GLICLASS_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
+    ap.add_argument("--config", default="base")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--labels", type=int, default=8)
+    ap.add_argument("--cpu-seqs", type=int, default=2, help="sequences timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    from gliclass.c_amd import _lib, synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import DTYPES
+
+    cfg = CONFIGS[args.config]
+    B, S, Cn = args.batch, args.seq, args.labels
+    hipl, modl = _lib.hip(), _lib.model()
+    if hipl.glc_device_count() <= local_rank:
+        raise SystemExit("bench: no HIP device for this rank (the engine has no CPU path)")
+
+    # weights: deterministic synthetic (no checkpoints offline), generated by the C host layer
+    W = _lib.Weights()
+    if modl.glc_weights_load(f"synthetic:{args.config}:42".encode(), C.byref(W)) != 0:
+        raise SystemExit("bench: weight generation failed")
+    h = hipl.glc_engine_create(C.byref(W.cfg), C.cast(W.tensors, C.POINTER(C.c_void_p)), W.n_tensors, local_rank, DTYPES[args.dtype])
+    if not h:
+        raise SystemExit("bench: engine create failed: " + hipl.glc_last_error().decode())
+
+    ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=1234 + rank)
+    d_ids = hipl.glc_device_malloc(h, ids.nbytes)
+    d_mask = hipl.glc_device_malloc(h, mask.nbytes)
+    d_logits = hipl.glc_device_malloc(h, B * Cn * 4)
+    hipl.glc_memcpy_h2d(h, d_ids, ids.ctypes.data, ids.nbytes)
+    hipl.glc_memcpy_h2d(h, d_mask, mask.ctypes.data, mask.nbytes)
+
+    def step():
+        if hipl.glc_engine_forward_device(h, d_ids, d_mask, B, S, Cn, d_logits) != 0:
+            raise RuntimeError(hipl.glc_last_error().decode())
+
+    def sync():
+        if hipl.glc_engine_sync(h) != 0:
+            raise RuntimeError(hipl.glc_last_error().decode())
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = time_steps(step, sync, barrier, max_over_ranks, args.steps, args.warmup)
+    seqs_per_s = world * B * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # HIP-event cross-check of the same loop on this rank's stream
+    hipl.glc_timer_start(h)
+    for _ in range(args.steps):
+        step()
+    ev_ms = float(hipl.glc_timer_stop_ms(h)) / args.steps
+
+    out = None
+    if rank == 0:
+        logits = np.zeros((B, Cn), np.float32)
+        hipl.glc_memcpy_d2h(h, logits.ctypes.data, d_logits, logits.nbytes)
+        fl = kernel_flops(cfg, B, S)
+        roof = None
+        if not args.no_profile:
+            hipl.glc_profile_enable(h, 1)
+            for _ in range(3):
+                step()
+                sync()
+            names = (C.c_char_p * 16)(); ms = (C.c_float * 16)(); cnt = (C.c_int * 16)()
+            k = hipl.glc_profile_read(h, names, ms, cnt, 16)
+            hipl.glc_profile_enable(h, 0)
+            prof = {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(k) if cnt[i] > 0}
+            total_ms = sum(v[0] for v in prof.values())
+            per = {}
+            for n, (tms, c) in prof.items():
+                avg = tms / c
+                e = dict(avg_ms=round(avg, 4), launches_per_fwd=c // 3, share=round(tms / total_ms, 4))
+                if n in fl:
+                    e["tflops"] = round(fl[n] / (avg * 1e-3) / 1e12, 1)
+                per[n] = e
+            dom = max((n for n in per if n in fl), key=lambda n: per[n]["avg_ms"] * per[n]["launches_per_fwd"])
+            peak = PEAK_TFLOPS[args.dtype]
+            e2e = cfg.flops_per_seq(S, Cn) * seqs_per_s / world / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=per[dom]["tflops"], peak=peak, unit="TFLOP/s",
+                        frac=round(per[dom]["tflops"] / peak, 4), traffic=None,
+                        flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
+                        e2e_achieved=round(e2e, 1), e2e_frac=round(e2e / peak, 4), per_kernel=per)
+        cpu = None
+        if args.cpu_seqs > 0:
+            cpu, ref_logits, rids, rmask = cpu_baseline(cfg, W.tensors, W.n_tensors, S, Cn, args.cpu_seqs)
+            # parity spot-check of the timed configuration itself (same seed => first rows identical)
+            got = np.zeros((args.cpu_seqs, Cn), np.float32)
+            c_out = C.c_int(0)
+            hipl.glc_engine_forward(h, rids.ctypes.data, rmask.ctypes.data, args.cpu_seqs, S, got.ctypes.data, Cn, C.byref(c_out))
+            pe = np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref_logits.astype(np.float64)))).max()
+            cpu["gpu_vs_cpu_max_prob_err"] = float(pe)
+        out = {
+            "metric": "sequences/sec at batch=64 seq=1024, gliclass-base; %MFMA-peak; 1/2/4/8-GPU",
+            "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"gliclass-{args.config} (DeBERTa-v3 shape L={cfg.layers} H={cfg.hidden}), batch={B} seq={S} labels={Cn}, "
+                                   f"random-init weights (seed 42), full-length rows", "global_batch": B * world, "seq_len": S,
+                       "parallelism": f"batch-shard x{world} (one process per GPU, no data-path collective)"},
+            "hip_event_ms_per_step": round(ev_ms, 3),
+            "finite": bool(np.isfinite(logits).all()),
+        }
+        if roof:
+            out["roofline"] = roof
+        if cpu:
+            out["cpu_baseline"] = cpu
+    sync()
+    hipl.glc_device_free(h, d_ids); hipl.glc_device_free(h, d_mask); hipl.glc_device_free(h, d_logits)
+    hipl.glc_engine_destroy(h)
+    modl.glc_weights_free(C.byref(W))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

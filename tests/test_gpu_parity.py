@@ -1,0 +1,179 @@
+"""GPU (-m gpu): parity of the HIP path against the oracle and the committed golden fixtures, all
+through the C-ABI (include/gliclass_hip.h and include/model.h).
+
+Tolerances (per-label probabilities, the quantity north_star bounds):
+  f32  operands: 1e-3 is the bar (BASELINE.json); measured ~1e-6, asserted at 1e-4.
+  f16 / bf16 operands (the MFMA throughput modes): every GEMM/attention operand is rounded to 11 / 8
+  significant bits, which random-walks through the layers; asserted at the measured envelopes
+  TOL_16 below and REPORTED against the 1e-3 bar in DESIGN.md (f16 sits around the bar, bf16 above).
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_PROB = {"f32": 1e-4, "f16": 4e-3, "bf16": 3e-2}
+TOL_HID = {"f32": 2e-4, "f16": 4e-2, "bf16": 3e-1}
+GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*_b*_s*.npz")))
+
+
+def sig(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
+
+
+@pytest.fixture(scope="module")
+def engines(weights_for):
+    from gliclass.c_amd.engine import Engine
+    cache = {}
+
+    def get(cname, dtype):
+        if (cname, dtype) not in cache:
+            cfg, w = weights_for(cname)
+            cache[(cname, dtype)] = Engine(cfg, w, dtype=dtype)
+        return cache[(cname, dtype)]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("case", GOLD)
+def test_golden_fixtures(case, dtype, engines, golden_dir):
+    g = np.load(os.path.join(golden_dir, case + ".npz"))
+    cname = str(g["config"])
+    if cname == "small" and dtype == "bf16":
+        pytest.skip("one 16-bit run of the 141M-parameter case is enough")
+    eng = engines(cname, dtype)
+    ids, mask = g["ids"].astype(np.int64), g["mask"].astype(np.int64)
+    B, S = ids.shape
+    eng.keep_hidden(True)
+    eng.set_attention_impl(0)
+    logits = eng.forward(ids, mask)
+    eng.keep_hidden(False)
+    assert logits.shape == g["logits"].shape and np.isfinite(logits).all()
+    assert eng.last_c == int(g["counts"].max())
+    assert np.abs(sig(logits) - g["probs"]).max() <= TOL_PROB[dtype]
+    pos, hs = g["sample_pos"], g["hidden_samples"]
+    valid = mask[:, pos][:, : hs.shape[2]].astype(bool)
+    for which in range(eng.cfg.layers + 1):
+        got = eng.hidden(which, B, S)[:, pos, :][..., : hs.shape[-1]][:, : hs.shape[2]]
+        assert np.abs(got[valid] - hs[which][valid]).max() <= TOL_HID[dtype], which
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_band_attention_equals_simple_attention(dtype, engines, weights_for):
+    """The MFMA Toeplitz-band kernel and the straightforward kernel read the same operands, so their
+    layer outputs must agree to accumulation-order noise — including S > 512 (clamped buckets)."""
+    from gliclass.c_amd import synth
+    cfg, _ = weights_for("tiny")
+    eng = engines("tiny", dtype)
+    for (B, S, seed) in ((3, 77, 1), (2, 640, 2), (1, 1100, 3)):
+        ids, mask, _ = synth.make_inputs(cfg, B, S, 2, seed=seed, ragged=True)
+        outs = []
+        for impl in (1, 2):
+            eng.set_attention_impl(impl)
+            eng.keep_hidden(True)
+            eng.forward(ids, mask)
+            outs.append(eng.hidden(1, B, S))
+        eng.set_attention_impl(0)
+        eng.keep_hidden(False)
+        m = mask.astype(bool)
+        tol = 2e-2 if dtype == "f16" else 1.5e-1
+        assert np.abs(outs[0][m] - outs[1][m]).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_live_oracle_sweep(dtype, engines, weights_for):
+    """Seeded shapes not in the fixtures: odd S, S not a multiple of 32/64, B not a multiple of anything,
+    rows without labels, a fully padded tail row, S=1."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for("mini")
+    eng = engines("mini", dtype)
+    for (B, S, Cn, lpr, seed) in ((5, 33, 3, [3, 0, 1, 2, 3], 11), (1, 129, 1, None, 12), (7, 64, 2, None, 13), (2, 513, 4, [4, 1], 14)):
+        ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=seed, ragged=True, labels_per_row=lpr)
+        ref = oracle_c.forward(cfg, w, ids, mask)
+        got = eng.forward(ids, mask)
+        assert got.shape == ref.shape
+        assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (B, S)
+    ids = np.array([[cfg.cls_id]], np.int64)
+    got = eng.forward(ids, np.ones_like(ids), c_alloc=0)
+    assert got.shape == (1, 0)
+
+
+def test_rows_are_independent_and_order_free(engines, weights_for):
+    """Size-independent properties at a larger shape: permuting batch rows permutes logits; a row's
+    logits do not depend on its batch mates (what makes the batch shard across GPUs)."""
+    from gliclass.c_amd import synth
+    cfg, _ = weights_for("mini")
+    eng = engines("mini", "f16")
+    ids, mask, _ = synth.make_inputs(cfg, 16, 512, 4, seed=5, ragged=True)
+    base = eng.forward(ids, mask)
+    perm = np.random.RandomState(0).permutation(16)
+    assert np.array_equal(eng.forward(ids[perm], mask[perm]), base[perm])
+    lo = eng.forward(ids[:8], mask[:8])
+    hi = eng.forward(ids[8:], mask[8:])
+    assert np.array_equal(np.concatenate([lo, hi]), base)
+    n = int(mask[3].sum())
+    solo = eng.forward(ids[3:4, :n], mask[3:4, :n])          # trimmed to its own length (different Sp)
+    assert np.abs(sig(solo) - sig(base[3:4])).max() <= 2e-3
+
+
+def test_model_h_drop_in_path(weights_for):
+    """The reference call sequence (/root/reference/main.c:83-99,141-150 + parallel_processor.c:44,88) through
+    include/model.h: initialize_ort_api -> env -> session -> prepare_input_tensors -> run_inference ->
+    OrtApi introspection -> ReleaseValue, checked against the oracle."""
+    import oracle_c
+    from gliclass.c_amd import _lib, synth
+    cfg, w = weights_for("tiny")
+    m = _lib.model()
+    os.environ["GLICLASS_DTYPE"] = "f32"
+    m.initialize_ort_api()
+    env = m.initialize_ort_environment()
+    sess = m.create_ort_session(env, b"synthetic:tiny:42", 8)
+    assert sess and m.glc_session_num_devices(sess) == 1
+    ids, mask, _ = synth.make_inputs(cfg, 3, 50, 3, seed=21, ragged=True, labels_per_row=[3, 1, 2])
+    i32, m32 = ids.astype(np.int32), mask.astype(np.int32)
+    rows_i = (C.POINTER(C.c_int) * 3)(*[i32[b].ctypes.data_as(C.POINTER(C.c_int)) for b in range(3)])
+    rows_m = (C.POINTER(C.c_int) * 3)(*[m32[b].ctypes.data_as(C.POINTER(C.c_int)) for b in range(3)])
+    tok = _lib.TokenizedInputs(rows_i, rows_i, rows_m, 3, 50)
+    a, b = C.POINTER(_lib.OrtValue)(), C.POINTER(_lib.OrtValue)()
+    assert m.prepare_input_tensors(C.byref(tok), C.byref(a), C.byref(b)) == 0
+    out = m.run_inference(sess, a, b)
+    assert out and out.contents.type == 1 and list(out.contents.dims[:2]) == [3, 3]
+    got = np.ctypeslib.as_array(C.cast(out.contents.data, C.POINTER(C.c_float)), shape=(3, 3)).copy()
+    ref = oracle_c.forward(cfg, w, ids, mask)
+    assert np.abs(sig(got) - sig(ref)).max() <= 1e-4
+    # batch sharding extension: 3 batches through parallel_inference give the same tensors
+    ins_a = (C.POINTER(_lib.OrtValue) * 3)(a, a, a)
+    ins_b = (C.POINTER(_lib.OrtValue) * 3)(b, b, b)
+    outs = (C.POINTER(_lib.OrtValue) * 3)()
+    m.parallel_inference(sess, ins_a, ins_b, 3, outs)
+    for o in outs:
+        assert o and np.array_equal(np.ctypeslib.as_array(C.cast(o.contents.data, C.POINTER(C.c_float)), shape=(3, 3)), got)
+    del os.environ["GLICLASS_DTYPE"]
+
+
+def test_full_size_base_row_vs_oracle(weights_for):
+    """BASELINE config c3's model (gliclass-base shape) at S=1024: one row against the fp32 CPU oracle,
+    plus batch-position invariance at B=8."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w = weights_for("base")
+    ids, mask, _ = synth.make_inputs(cfg, 8, 1024, 8, seed=1234)
+    ref = oracle_c.forward(cfg, w, ids[:1], mask[:1])
+    res = {}
+    for dtype in ("f32", "f16"):
+        eng = Engine(cfg, w, dtype=dtype)
+        got = eng.forward(ids, mask) if dtype == "f16" else eng.forward(ids[:2], mask[:2])
+        eng.close()
+        assert np.isfinite(got).all()
+        res[dtype] = float(np.abs(sig(got[:1]) - sig(ref)).max())
+    print("base S=1024 max prob err vs oracle:", res)
+    assert res["f32"] <= 1e-4
+    assert res["f16"] <= 1e-2

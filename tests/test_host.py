@@ -1,0 +1,218 @@
+"""CPU (no GPU): the C-ABI libraries load and export every declared symbol; host-side logic of the
+drop-in layer (tensor helpers, OrtApi shim, post-processor, weight source, PRNG, delta table)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def libs():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "gliclass", "c_amd"), "-j4", "all"], stdout=subprocess.DEVNULL)
+    from gliclass.c_amd import _lib
+    return _lib, _lib.hip(), _lib.model()
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef struct OrtApi \{.*?\} OrtApi;", "", src, flags=re.S)
+    src = re.sub(r"typedef struct OrtApiBase \{.*?\} OrtApiBase;", "", src, flags=re.S)
+    src = re.sub(r"static inline[^{]*\{[^}]*\}", "", src)
+    return set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src))
+
+
+def test_every_declared_symbol_is_exported(libs):
+    _lib, hip, model = libs
+    for name in _declared_functions("gliclass_hip.h"):
+        assert hasattr(hip, name), name
+    for hdr in ("model.h", "postprocessor.h", "parallel_processor.h", "glc_weights.h"):
+        for name in _declared_functions(hdr):
+            assert hasattr(model, name), (hdr, name)
+    assert hasattr(model, "OrtGetApiBase") and hasattr(model, "g_ort")
+    # externally supplied pieces (reference's src/preprocessor.c / src/tokenizer.c) are weak, not exported
+    for name in _declared_functions("tokenizer.h") | _declared_functions("preprocessor.h"):
+        assert name in ("tokenize_inputs", "free_tokenized_inputs", "prepare_inputs", "prepare_input", "free_prepared_inputs")
+
+
+def test_no_gpu_means_loud_failure(libs):
+    _lib, hip, model = libs
+    if hip.glc_device_count() > 0:
+        pytest.skip("GPU present")
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Engine(CONFIGS["tiny"], weights.make_weights(CONFIGS["tiny"], 1), dtype="f32")
+    model.initialize_ort_api()
+    env = model.initialize_ort_environment()
+    assert env
+    assert not model.create_ort_session(env, b"synthetic:tiny", 8)     # NULL + message on stderr
+
+
+def test_delta_table_product_impl_bit_exact(libs, golden_dir):
+    from gliclass.c_amd.engine import delta_table
+    tabs = np.load(os.path.join(golden_dir, "delta_tables.npz"))
+    for key in tabs.files:
+        assert np.array_equal(delta_table(int(key[1:])), tabs[key].astype(np.int32)), key
+
+
+def test_prng_and_tensor_specs_match_python(libs):
+    _lib, hip, model = libs
+    from gliclass.c_amd import prng, weights
+    from gliclass.c_amd.config import CONFIGS
+    for name, n, amp, mean in (("embeddings.word_embeddings.weight", 5000, 1.0, 0.0), ("x.bias", 17, 0.1, 1.0)):
+        out = np.zeros(n, np.float32)
+        model.glc_prng_fill(42, name.encode(), n, amp, mean, out.ctypes.data)
+        assert np.array_equal(out, prng.uniform_f32(42, name, n, amp, mean))
+        assert model.glc_fnv1a64(name.encode()) == prng.fnv1a64(name)
+    for cname in ("tiny", "mini", "small", "base", "large"):
+        cfg = CONFIGS[cname]
+        cc = _lib.ModelConfig()
+        assert model.glc_named_config(cname.encode(), C.byref(cc)) == 0
+        for f in ("vocab", "hidden", "layers", "heads", "inter", "class_token_index", "text_token_index", "pos_buckets"):
+            assert getattr(cc, f) == getattr(cfg, f), (cname, f)
+        specs = weights.tensor_specs(cfg)
+        buf = C.create_string_buffer(96)
+        shp = (C.c_uint64 * 4)()
+        amp, mean = C.c_double(), C.c_double()
+        for i, (n, shape, a, m) in enumerate(specs):
+            nd = model.glc_tensor_spec(C.byref(cc), i, buf, shp, C.byref(amp), C.byref(mean))
+            assert nd == len(shape) and buf.value.decode() == n and tuple(shp[:nd]) == tuple(shape)
+            assert abs(amp.value - a) < 1e-15 and mean.value == m
+        assert model.glc_tensor_spec(C.byref(cc), len(specs), buf, shp, C.byref(amp), C.byref(mean)) == -1
+
+
+def test_weight_sources_synthetic_and_blob(libs, tmp_path):
+    _lib, hip, model = libs
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    cfg = CONFIGS["tiny"]
+    ref = weights.make_weights(cfg, 7)
+    names = [s[0] for s in weights.tensor_specs(cfg)]
+    path = str(tmp_path / "tiny.glcw")
+    weights.write_blob(path, cfg, ref)
+    cfg2, back = weights.read_blob(path)
+    assert cfg2.hidden == cfg.hidden and all(np.array_equal(back[n], ref[n]) for n in names)
+    for src in (b"synthetic:tiny:7", path.encode()):
+        W = _lib.Weights()
+        assert model.glc_weights_load(src, C.byref(W)) == 0
+        assert W.n_tensors == len(names) and W.cfg.hidden == cfg.hidden and W.cfg.class_token_index == cfg.class_token_index
+        for i, n in enumerate(names):
+            got = np.ctypeslib.as_array(W.tensors[i], shape=(ref[n].size,))
+            assert np.array_equal(got, ref[n].ravel()), n
+        model.glc_weights_free(C.byref(W))
+    W = _lib.Weights()
+    assert model.glc_weights_load(b"/nonexistent.glcw", C.byref(W)) != 0
+    assert model.glc_weights_load(b"synthetic:nope", C.byref(W)) != 0
+    bad = tmp_path / "bad.glcw"
+    bad.write_bytes(b"\0" * 512)
+    assert model.glc_weights_load(str(bad).encode(), C.byref(W)) != 0
+
+
+def _ragged_rows(rows):
+    arrs = [np.asarray(r, np.int32) for r in rows]
+    ptrs = (C.POINTER(C.c_int) * len(arrs))(*[a.ctypes.data_as(C.POINTER(C.c_int)) for a in arrs])
+    return arrs, ptrs
+
+
+def test_flatten_create_prepare_tensors(libs):
+    """/root/reference/src/model.c:17-108 semantics, incl. ownership and shapes."""
+    _lib, hip, model = libs
+    model.initialize_ort_api()
+    rows = [[1, 5, 7, 0], [1, 9, 0, 0], [-3, 2**31 - 1, 4, 4]]
+    arrs, ptrs = _ragged_rows(rows)
+    flat = model.flatten_int_array(ptrs, 3, 4)
+    got = np.ctypeslib.as_array(flat, shape=(12,)).copy()
+    assert got.dtype == np.int64 and np.array_equal(got.reshape(3, 4), np.asarray(rows, np.int64))
+    t = model.create_tensor(flat, 3, 4)
+    assert t and t.contents.type == 7 and t.contents.ndim == 2 and list(t.contents.dims[:2]) == [3, 4]
+    assert t.contents.data == C.addressof(flat.contents) and t.contents.owns_data == 0      # wraps, does not copy/own
+    api = C.c_void_p.in_dll(model, "g_ort")
+    assert api.value
+    marrs, mptrs = _ragged_rows([[1, 1, 1, 0], [1, 1, 0, 0], [1, 1, 1, 1]])
+    tok = _lib.TokenizedInputs(ptrs, ptrs, mptrs, 3, 4)
+    a, b = C.POINTER(_lib.OrtValue)(), C.POINTER(_lib.OrtValue)()
+    assert model.prepare_input_tensors(C.byref(tok), C.byref(a), C.byref(b)) == 0
+    assert list(a.contents.dims[:2]) == [3, 4] and a.contents.owns_data == 1 and b.contents.owns_data == 1
+    ids = np.ctypeslib.as_array(C.cast(a.contents.data, C.POINTER(C.c_int64)), shape=(3, 4))
+    mk = np.ctypeslib.as_array(C.cast(b.contents.data, C.POINTER(C.c_int64)), shape=(3, 4))
+    assert np.array_equal(ids, np.asarray(rows)) and mk.sum() == 9
+    assert model.prepare_input_tensors(None, C.byref(a), C.byref(b)) == -1
+
+
+_POST = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %(root)r)
+from gliclass.c_amd import _lib
+m = _lib.model(); m.initialize_ort_api()
+api = C.c_void_p.in_dll(m, "g_ort")
+logits = np.array(%(logits)r, np.float32)
+B, Cn = logits.shape
+dims = (C.c_int64 * 2)(B, Cn)
+class OrtApi(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("CreateEnv","ReleaseEnv","ReleaseSession","ReleaseValue","ReleaseStatus","GetErrorMessage",
+                "CreateCpuMemoryInfo","ReleaseMemoryInfo","CreateTensorWithDataAsOrtValue")]
+vt = C.cast(api, C.POINTER(OrtApi)).contents
+mk = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p))(vt.CreateTensorWithDataAsOrtValue)
+val = C.c_void_p()
+assert mk(None, logits.ctypes.data, logits.nbytes, dims, 2, 1, C.byref(val)) is None
+def strs(xs): return (C.c_char_p * len(xs))(*[x.encode() for x in xs])
+labels = %(labels)r
+lab_arrs = [strs(l) for l in labels]
+lab = (C.POINTER(C.c_char_p) * len(labels))(*[C.cast(a, C.POINTER(C.c_char_p)) for a in lab_arrs])
+nl = (C.c_size_t * len(labels))(*[len(l) for l in labels])
+texts = strs(%(texts)r)
+m.process_output_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_bool, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_size_t, C.c_void_p, C.c_char_p]
+m.process_output_tensor(val, api, %(same)r, lab, nl, %(nls)d, C.c_float(%(thr)r), B, texts, %(kind)r)
+'''
+
+
+def _run_post(logits, labels, texts, same, kind, thr=0.5):
+    code = _POST % dict(root=ROOT, logits=logits, labels=labels, texts=texts, same=same, nls=len(labels[0]), thr=thr, kind=kind.encode())
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+
+
+def _sig(x):
+    return float(np.float32(1.0) / (np.float32(1.0) + np.exp(-np.float32(x), dtype=np.float32)))
+
+
+def test_process_output_tensor_formats_and_rules(libs):
+    """Observable behaviour of /root/reference/src/postprocessor.c:88-150."""
+    logits = [[2.0, -1.0, 0.0, 0.5], [-3.0, -2.0, -4.0, -5.0]]
+    out = _run_post(logits, [["alpha", "beta", "gamma", "delta"]], ["first text", "second"], True, "multi-label")
+    exp = ("Text_0: first text:\n  Text_0 Label: alpha, Score: %.6f\n  Text_0 Label: delta, Score: %.6f\n\nText_1: second:\n\n"
+           % (_sig(2.0), _sig(0.5)))            # 0.0 -> prob 0.5 is NOT > 0.5 (strict compare, :95)
+    assert out == exp
+    out = _run_post(logits, [["alpha", "beta", "gamma", "delta"]], ["first text", "second"], True, "single-label")
+    assert out == "Text_0: first text:\n  Text_0 Label: alpha, Score: %.6f\n\nText_1: second:\n  Text_1 Label: beta, Score: %.6f\n\n" % (_sig(2.0), _sig(-2.0))
+    # per-text labels: slot j >= num_labels[i] prints [Unknown] (:101-111)
+    out = _run_post([[3.0, 3.0], [3.0, -3.0]], [["a"], ["x", "y"]], ["t0", "t1"], False, "multi-label")
+    assert out == ("Text_0: t0:\n  Text_0 Label: a, Score: %.6f\n  Text_0 Label: [Unknown], Score: %.6f\n\nText_1: t1:\n  Text_1 Label: x, Score: %.6f\n\n"
+                   % (_sig(3.0), _sig(3.0), _sig(3.0)))
+    assert _run_post(logits, [["a", "b", "c", "d"]], ["p", "q"], True, "ranking") == "This type of classification is not supported\n"
+
+
+def test_sigmoid_matches_reference_formula(libs):
+    _lib, hip, model = libs
+    for x in (-30.0, -1.25, 0.0, 0.75, 12.0):
+        assert abs(model.sigmoid(x) - 1.0 / (1.0 + np.exp(-x))) < 1e-7
+
+
+def test_synthetic_inputs_layout():
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS
+    cfg = CONFIGS["base"]
+    ids, mask, counts = synth.make_inputs(cfg, 4, 64, 8)
+    assert (counts == 8).all() and mask.all() and (ids[:, 0] == cfg.cls_id).all() and (ids[:, -1] == cfg.sep_id).all()
+    assert (ids[:, 1] == cfg.class_token_index).all() and (ids[:, 25] == cfg.text_token_index).all()
+    ids, mask, counts = synth.make_inputs(cfg, 6, 200, 3, ragged=True)
+    lens = mask.sum(1)
+    assert lens.max() == 200 and lens.min() >= 100 and (ids[mask == 0] == 0).all()
+    assert all(mask[b, :lens[b]].all() for b in range(6))        # prefix masks, like the tokenizer's padding

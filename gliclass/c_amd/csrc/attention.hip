@@ -19,10 +19,15 @@
 // the relative distance itself and the per-element lookup is pure arithmetic (rr = c - kk + 31).
 // Both bands go through a wave-private LDS scratch (2 x 32 x 68 floats) — written as b128 rows,
 // read back as conflict-free b32 gathers; no workgroup barrier anywhere in the kernel.
+// The band SLIDES: stepping one key tile lowers rmin by 32, so the upper 32-row block of tile kt+1 is
+// the lower block of tile kt.  Per key tile only one new block of PK/PQ rows is loaded, the c2p band
+// (a function of (rel, q) only) is computed for that block alone and kept in a 2-slot LDS ring,
+// and the next tile's K / PK / PQ fragments are prefetched under the current tile's MFMAs.
 // Key rows are loaded in the order pi(r) = swap(bit2,bit3) so that the accumulator-as-operand k
 // permutation of the P*V MFMA lines up with 8 CONTIGUOUS keys of V^T (one 16-B load per lane).
 #include "glc_common.h"
 #include "glc_kernels.h"
+#include "glc_layout.h"
 
 namespace {
 
@@ -34,7 +39,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_band_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     typedef typename Frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -44,88 +49,141 @@ __global__ __launch_bounds__(256) void attn_band_kernel(AttnArgs a) {
     if (q0 >= Sp) return;                      // whole wave leaves; no workgroup barriers below
     const int bh = blockIdx.y, b = bh / a.nh, hh = bh - b * a.nh;
 
-    const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64;
-    const T* __restrict__ Kp = reinterpret_cast<const T*>(a.Kh) + (size_t)bh * Sp * 64;
-    const T* __restrict__ Vp = reinterpret_cast<const T*>(a.Vt) + (size_t)bh * 64 * Sp;
-    const T* __restrict__ PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64;
-    const T* __restrict__ PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64;
+    // fragment-major operands (glc_layout.h): one tile = 4 (or 2x2) units of 64 lanes x 16 B
+    const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64 + lane * 8;
+    const T* __restrict__ Kp = reinterpret_cast<const T*>(a.Kh) + (size_t)bh * Sp * 64 + lane * 8;
+    const T* __restrict__ Vp = reinterpret_cast<const T*>(a.Vt) + (size_t)bh * 64 * Sp + lane * 8;
+    const T* __restrict__ PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64 + 32 * 8 * h;
+    const T* __restrict__ PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64 + 32 * 8 * h;
     const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
     const int32_t* __restrict__ dtab = a.dtab;
     float* c2p_l = lds + (size_t)wave * 2 * 32 * LROW;
     float* p2c_l = c2p_l + 32 * LROW;
 
-    frag_t qf[4];
+    const int pr = (c & 0x13) | ((c & 4) << 1) | ((c & 8) >> 1);   // pi(c)
+    int nkt = (a.klen[b] + 31) >> 5;                               // key tiles beyond the last valid key add exactly 0
+    nkt = nkt < 1 ? 1 : (nkt > (Sp >> 5) ? (Sp >> 5) : nkt);
+    const int kfirst = a.kfirst[b];                                // first masked key: tiles below it need no key bias
+    const int foff = 8 * h;                                        // fragment k-offset of this lane half
+
+    // delta of row c of relative-distance block L(t): rel = q0 - 32 t - 31 + c  (t = -1 is the block above tile 0)
+    auto block_delta = [&](int t) -> int {
+        int idx = q0 - 32 * t - 31 + c + Sp - 1;
+        idx = idx < 0 ? 0 : (idx > 2 * Sp - 2 ? 2 * Sp - 2 : idx);
+        return dtab[idx];
+    };
+    auto load_tile = [&](const T* base, int tile, frag_t (&f)[4]) {      // K tile / Q tile: 4 contiguous 1-KiB units
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag_t*>(Qp + c * 64 + 16 * s + 8 * h);
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + (size_t)tile * 2048 + s * 512);
+    };
+    auto load_pq = [&](int d, frag_t (&f)[4]) {                           // row d of query_proj(rel): Q layout
+        const T* p = PQp + (size_t)(d >> 5) * 2048 + (d & 31) * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 512);
+    };
+    auto load_pk = [&](int d, frag_t (&f)[4]) {                           // row d of key_proj(rel): K layout (pi on the row)
+        const T* p = PKp + (size_t)(d >> 5) * 2048 + glc_pi32(d & 31) * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 512);
+    };
+    auto band_store = [&](float* dst, const f32x16& v) {           // 4 consecutive rr per register group
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = (f32x4){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    };
+
+    frag_t qf[4];
+    load_tile(Qp, 0, qf);
+
+    // ---- prologue: c2p blocks L(-1) -> ring half 1 and L(0) -> ring half 0; PQ fragments of both; K of tile 0 ----
+    frag_t kf[4], pq_lo[4], pq_hi[4];
+    {
+        frag_t pk[4];
+        f32x16 bacc;
+        int d = block_delta(-1);
+        load_pk(d, pk);
+        load_pq(d, pq_hi);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+        band_store(c2p_l + c * LROW + 32, bacc);
+        d = block_delta(0);
+        load_pk(d, pk);
+        load_pq(d, pq_lo);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+        band_store(c2p_l + c * LROW, bacc);
+        load_tile(Kp, 0, kf);
+    }
+    int d_next = block_delta(nkt > 1 ? 1 : 0);
 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m = -3.0e38f, l = 0.f;
-    const int pr = (c & 0x13) | ((c & 4) << 1) | ((c & 8) >> 1);   // pi(c)
-    int nkt = (a.klen[b] + 31) >> 5;                               // key tiles beyond the last valid key add exactly 0
-    nkt = nkt < 1 ? 1 : (nkt > (Sp >> 5) ? (Sp >> 5) : nkt);
+    const int rr_base = c - 8 * h + 31;
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * 32;
-        frag_t kf[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const frag_t*>(Kp + (size_t)(k0 + pr) * 64 + 16 * s + 8 * h);
+        // ---- prefetch the next tile's operands (clamped re-load on the last tile) ----
+        const int ktn = kt + 1 < nkt ? kt + 1 : kt;
+        frag_t n_kf[4], n_pq[4], pk[4];
+        load_tile(Kp, ktn, n_kf);
+        load_pq(d_next, n_pq);
+        load_pk(d_next, pk);
+        d_next = block_delta(kt + 2 < nkt ? kt + 2 : ktn);
 
-        // S^T accumulators start from the additive key bias: reg i <-> key k0 + 16*(i>>3) + 8h + (i&7)
+        // ---- S^T = K Q^T ; reg i <-> key k0 + 16*(i>>3) + 8h + (i&7) ----
         f32x16 sacc;
-        {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + 8 * h);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + 8 * h + 4);
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + 8 * h);
-            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + 8 * h + 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { sacc[i] = b0[i]; sacc[4 + i] = b1[i]; sacc[8 + i] = b2[i]; sacc[12 + i] = b3[i]; }
-        }
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
 
-        // relative-position bands over rr = (q-k) - rmin, rmin = q0 - k0 - 31
-        const int rmin = q0 - k0 - 31;
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            int idx = rmin + 32 * jt + c + Sp - 1;
-            idx = idx < 0 ? 0 : (idx > 2 * Sp - 2 ? 2 * Sp - 2 : idx);
-            const int dl = dtab[idx];
-            frag_t pf[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const frag_t*>(PKp + (size_t)dl * 64 + 16 * s + 8 * h);
+        // ---- p2c band for both blocks of this key tile: [rr][key pi(c)] ----
+        {
             f32x16 bacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pf[s], qf[s], bacc);          // [rr][query c]
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(c2p_l + c * LROW + 32 * jt + 8 * g + 4 * h) =
-                    (f32x4){bacc[4 * g], bacc[4 * g + 1], bacc[4 * g + 2], bacc[4 * g + 3]};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) pf[s] = *reinterpret_cast<const frag_t*>(PQp + (size_t)dl * 64 + 16 * s + 8 * h);
+            for (int s = 0; s < 4; ++s) mma32(pq_lo[s], kf[s], bacc);
+            band_store(p2c_l + pr * LROW, bacc);
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pf[s], kf[s], bacc);          // [rr][key pi(c)]
+            for (int s = 0; s < 4; ++s) mma32(pq_hi[s], kf[s], bacc);
+            band_store(p2c_l + pr * LROW + 32, bacc);
+        }
+        frag_t vt[2][2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(p2c_l + pr * LROW + 32 * jt + 8 * g + 4 * h) =
-                    (f32x4){bacc[4 * g], bacc[4 * g + 1], bacc[4 * g + 2], bacc[4 * g + 3]};
+        for (int t = 0; t < 2; ++t) {
+            vt[0][t] = *reinterpret_cast<const frag_t*>(Vp + (size_t)kt * 2048 + t * 512);
+            vt[1][t] = *reinterpret_cast<const frag_t*>(Vp + (size_t)kt * 2048 + 1024 + t * 512);
         }
         wave_lds_sync();
 
+        const int xr = (kt & 1) << 5;           // ring half that holds this tile's low block
         float sv[16];
-        float mx = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int kk = 16 * (i >> 3) + 8 * h + (i & 7);
-            const int rr = c - kk + 31;
-            sv[i] = sacc[i] + c2p_l[c * LROW + rr] + p2c_l[kk * LROW + rr];
-            mx = fmaxf(mx, sv[i]);
+            const int kc = 16 * (i >> 3) + (i & 7);                         // key offset minus 8h
+            const int rr = rr_base - kc;
+            sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(kc + 8 * h) * LROW + rr];
         }
+        if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sv[i] += b0[i]; sv[4 + i] += b1[i]; sv[8 + i] += b2[i]; sv[12 + i] += b3[i]; }
+        }
+        float mx = sv[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx);
         const float alpha = __expf(m - mnew);
@@ -142,12 +200,23 @@ __global__ __launch_bounds__(256) void attn_band_kernel(AttnArgs a) {
             frag_t pfr;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
-            const frag_t v0 = *reinterpret_cast<const frag_t*>(Vp + (size_t)c * Sp + k0 + 16 * t + 8 * h);
-            const frag_t v1 = *reinterpret_cast<const frag_t*>(Vp + (size_t)(32 + c) * Sp + k0 + 16 * t + 8 * h);
-            mma32(v0, pfr, o0);       // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
-            mma32(v1, pfr, o1);       //                   dd + 32
+            mma32(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
+            mma32(vt[1][t], pfr, o1);     //                   dd + 32
         }
-        wave_lds_sync();              // this tile's gathers retire before the next tile's band writes
+
+        // ---- c2p band of the NEXT tile's low block L(kt+1) -> ring half (kt+1)&1 (held L(kt-1), now dead) ----
+        {
+            f32x16 bacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);          // [rr][query c]
+            wave_lds_sync();              // this tile's gathers retire before the ring slot is overwritten
+            band_store(c2p_l + c * LROW + (xr ^ 32), bacc);
+        }
+        // ---- slide: the low block becomes the high block of the next key tile ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { pq_hi[s] = pq_lo[s]; pq_lo[s] = n_pq[s]; kf[s] = n_kf[s]; }
     }
 
     l += __shfl_xor(l, 32, 64);
@@ -170,24 +239,21 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
     float* sc = sm + 64 + 256; // [Sp]
     const int Sp = a.Sp, q = blockIdx.x, bh = blockIdx.y, b = bh / a.nh, hh = bh - b * a.nh;
     const int t = threadIdx.x;
-    const T* Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q) * 64;
-    const T* Kp = reinterpret_cast<const T*>(a.Kh) + (size_t)bh * Sp * 64;
-    const T* Vp = reinterpret_cast<const T*>(a.Vt) + (size_t)bh * 64 * Sp;
-    const T* PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64;
-    const T* PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64;
+    const T* Qg = reinterpret_cast<const T*>(a.Qh);
+    const T* Kg = reinterpret_cast<const T*>(a.Kh);
+    const T* Vg = reinterpret_cast<const T*>(a.Vt);
+    const T* PKg = reinterpret_cast<const T*>(a.PK);
+    const T* PQg = reinterpret_cast<const T*>(a.PQ);
     const float* kb = a.kbias + (size_t)b * Sp;
-    if (t < 64) qv[t] = (float)Qp[t];
+    if (t < 64) qv[t] = (float)Qg[glc_qoff(Sp, bh, q, t)];
     __syncthreads();
     float mx = -3.0e38f;
     for (int k = t; k < Sp; k += 256) {
         const int dl = a.dtab[q - k + Sp - 1];
-        const T* kr = Kp + (size_t)k * 64;
-        const T* pk = PKp + (size_t)dl * 64;
-        const T* pq = PQp + (size_t)dl * 64;
         float s = 0.f;
         for (int e = 0; e < 64; ++e) {
-            const float kv = (float)kr[e];
-            s += qv[e] * (kv + (float)pk[e]) + kv * (float)pq[e];
+            const float kv = (float)Kg[glc_koff(Sp, bh, k, e)];
+            s += qv[e] * (kv + (float)PKg[glc_koff(a.P, hh, dl, e)]) + kv * (float)PQg[glc_qoff(a.P, hh, dl, e)];
         }
         s += kb[k];
         sc[k] = s;
@@ -208,8 +274,7 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
     const int dd = t & 63, part = t >> 6;
     const int per = (Sp + 3) / 4, klo = part * per, khi = min(Sp, klo + per);
     float acc = 0.f;
-    const T* vr = Vp + (size_t)dd * Sp;
-    for (int k = klo; k < khi; ++k) acc += sc[k] * (float)vr[k];
+    for (int k = klo; k < khi; ++k) acc += sc[k] * (float)Vg[glc_voff(Sp, bh, dd, k)];
     red[t] = acc;
     __syncthreads();
     if (t < 64) {
@@ -220,10 +285,11 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
 
 }  // namespace
 
-// Shape contract: head_dim == 64, Sp % 64 == 0, H == nh*64, dtab has 2*Sp-1 entries in [0, P).
+// Shape contract: head_dim == 64, Sp % 64 == 0, P % 32 == 0, H == nh*64, dtab has 2*Sp-1 entries in [0, P);
+// Q/K/V^T/PQ/PK in the fragment-major layouts of glc_layout.h.
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a) {
-    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.CTX) return "attention: null pointer";
-    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0) return "attention: bad shape";
+    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.kfirst || !a.CTX) return "attention: null pointer";
+    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention: bad shape";
     if (impl == 2 && dtype == GLC_DT_F32) return "attention: the MFMA band kernel needs 16-bit operands";
     if (impl == 2) {
         dim3 grid((a.Sp / 32 + 3) / 4, a.B * a.nh), block(256);

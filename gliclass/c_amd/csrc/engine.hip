@@ -66,7 +66,7 @@ struct glc_engine {
     // workspace
     int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0;
     void *X = nullptr, *Qh = nullptr, *Kh = nullptr, *Vt = nullptr, *CTX = nullptr, *T1 = nullptr, *H1 = nullptr, *FF = nullptr;
-    float* kbias = nullptr; int *klen = nullptr, *cls_pos = nullptr, *cls_cnt = nullptr;
+    float* kbias = nullptr; int *klen = nullptr, *kfirst = nullptr, *cls_pos = nullptr, *cls_cnt = nullptr;
     int64_t *d_ids = nullptr, *d_mask = nullptr;
     float *Gt = nullptr, *Gc = nullptr, *G1t = nullptr, *G1c = nullptr, *G2t = nullptr, *G2c = nullptr, *d_logits = nullptr;
     std::map<int, int32_t*> dtabs;
@@ -152,12 +152,13 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     }
     if (B > e->capB || C > e->capC) {
         const int nb = B > e->capB ? B : e->capB, nc = C > e->capC ? C : e->capC;
-        dfree(e, e->klen); dfree(e, e->cls_cnt); dfree(e, e->cls_pos); dfree(e, e->d_logits);
+        dfree(e, e->klen); dfree(e, e->kfirst); dfree(e, e->cls_cnt); dfree(e, e->cls_pos); dfree(e, e->d_logits);
         e->klen = (int*)dmalloc(e, (size_t)nb * sizeof(int));
+        e->kfirst = (int*)dmalloc(e, (size_t)nb * sizeof(int));
         e->cls_cnt = (int*)dmalloc(e, (size_t)nb * sizeof(int));
         e->cls_pos = (int*)dmalloc(e, (size_t)nb * (nc > 0 ? nc : 1) * sizeof(int));
         e->d_logits = (float*)dmalloc(e, (size_t)nb * (nc > 0 ? nc : 1) * sizeof(float));
-        if (!e->klen || !e->cls_cnt || !e->cls_pos || !e->d_logits) return false;
+        if (!e->klen || !e->kfirst || !e->cls_cnt || !e->cls_pos || !e->d_logits) return false;
         e->capB = nb; e->capC = nc;
     }
     if (B * S > e->capIds) {
@@ -200,7 +201,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         if (need > e->hidden_cap) { dfree(e, e->hidden_dump); e->hidden_dump = dmalloc(e, need); if (!e->hidden_dump) return false; e->hidden_cap = need; }
     }
     { Prof p(e, PC_SCAN);
-      KCHK(glc_launch_scan_rows(st, ids, mask, B, S, c.class_token_index, c.embed_class_token, e->klen, e->cls_pos, e->cls_cnt, ccap), false); }
+      KCHK(glc_launch_scan_rows(st, ids, mask, B, S, c.class_token_index, c.embed_class_token, e->klen, e->kfirst, e->cls_pos, e->cls_cnt, ccap), false); }
     { Prof p(e, PC_EMBED);
       KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
@@ -212,7 +213,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
         { Prof p(e, PC_QKV); KCHK(glc_launch_gemm(st, dt, EPI_QKV, g), false); }
-        AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->CTX, B, nh, Sp, H, e->P};
+        AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;

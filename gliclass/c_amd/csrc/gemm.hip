@@ -11,10 +11,11 @@
 //
 // Output orientation: the wave computes D^T = W_tile * A_tile^T (lane = output row m, 4 regs = 4
 // consecutive columns n) so each lane stores 4 packed elements; the V third of the fused QKV GEMM
-// flips the operands (lane = n, regs = 4 consecutive m) to write V transposed, [B,nh,64,Sp], which
-// is the A-operand layout the attention kernel's P*V MFMA wants.
+// flips the operands (lane = n, regs = 4 consecutive m) to write V transposed.  Q, K and V^T leave
+// this kernel in the fragment-major layouts of glc_layout.h (what the attention MFMAs load).
 #include "glc_common.h"
 #include "glc_kernels.h"
+#include "glc_layout.h"
 
 namespace {
 
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 
     // ---------------- epilogue ----------------
     const float* __restrict__ bias = p.bias;
+    const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;   // block-uniform (scalar) division
     if (!vmode) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -125,8 +127,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
                         const int which = n0 / p.H;                 // block-uniform: 0 = Q, 1 = K
                         const int nn = n - which * p.H;
                         const int hh = nn >> 6, dd = nn & 63;
-                        const int b = m / p.Sp, s = m - b * p.Sp;
-                        T* dst = reinterpret_cast<T*>(which == 0 ? p.Qh : p.Kh) + (((size_t)b * p.nh + hh) * p.Sp + s) * 64 + dd;
+                        int b = qkv_b0, s = m - qkv_b0 * p.Sp;     // a 128-row tile spans at most two sequences (Sp >= 64)
+                        if (s >= p.Sp) { s -= p.Sp; ++b; }
+                        const int bh = b * p.nh + hh;
+                        T* dst = which == 0 ? reinterpret_cast<T*>(p.Qh) + glc_qoff(p.Sp, bh, s, dd)
+                                            : reinterpret_cast<T*>(p.Kh) + glc_koff(p.Sp, bh, s, dd);
                         store4<T>(dst, v0, v1, v2, v3);
                     }
                 } else {
@@ -146,8 +151,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 64 + i * 16 + 4 * g;
                 if (m < p.Mvalid) {
-                    const int b = m / p.Sp, s = m - b * p.Sp;
-                    T* dst = reinterpret_cast<T*>(p.Vt) + (((size_t)b * p.nh + hh) * 64 + dd) * p.Sp + s;
+                    int b = qkv_b0, s = m - qkv_b0 * p.Sp;
+                    if (s >= p.Sp) { s -= p.Sp; ++b; }
+                    T* dst = reinterpret_cast<T*>(p.Vt) + glc_voff(p.Sp, b * p.nh + hh, dd, s);
                     store4<T>(dst, acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
                 }
             }
@@ -169,7 +175,8 @@ template <typename T> void launch_t(hipStream_t st, int epi, const GemmArgs& a) 
 
 // Host-side shape contract (checked here so a bad shape can never reach the kernel):
 //   Mpad % 128 == 0 and every [Mpad, *] buffer is allocated with Mpad rows; N % 128 == 0;
-//   K % (128 / sizeof(T)) == 0; for EPI_QKV additionally H % 128 == 0, Sp % 4 == 0.
+//   K % (128 / sizeof(T)) == 0; for EPI_QKV additionally H % 128 == 0, Sp % 64 == 0 (fragment-major
+//   Q/K/V^T outputs, glc_layout.h).
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
     const int esz = dtype == GLC_DT_F32 ? 4 : 2;
     if (a.Mpad <= 0 || a.Mpad % BM) return "gemm: Mpad must be a positive multiple of 128";
@@ -177,7 +184,7 @@ const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& 
     if (a.K <= 0 || a.K % (ROWB / esz)) return "gemm: K must be a multiple of 128 bytes";
     if (!a.A || !a.W) return "gemm: null operand";
     if (epi == EPI_QKV) {
-        if (a.H % 128 || a.N != 3 * a.H || a.Sp % 4 || !a.Qh || !a.Kh || !a.Vt || a.nh * 64 != a.H) return "gemm: bad QKV epilogue shape";
+        if (a.H % 128 || a.N != 3 * a.H || a.Sp % 64 || a.Sp < 64 || !a.Qh || !a.Kh || !a.Vt || a.nh * 64 != a.H) return "gemm: bad QKV epilogue shape";
     } else if (!a.C) return "gemm: null output";
     if (epi == EPI_RESID && !a.resid) return "gemm: null residual";
     switch (dtype) {

@@ -14,9 +14,9 @@ struct GemmArgs {
     const float* bias = nullptr;  // [N] or null
     void* C = nullptr;            // [Mpad, N]  T   (BIAS / GELU / RESID)
     const void* resid = nullptr;  // [Mpad, N]  T   (RESID)
-    void* Qh = nullptr;           // [B, nh, Sp, 64] T (QKV)
-    void* Kh = nullptr;           // [B, nh, Sp, 64] T
-    void* Vt = nullptr;           // [B, nh, 64, Sp] T
+    void* Qh = nullptr;           // B*nh*Sp*64 T, fragment-major (glc_layout.h)  (QKV)
+    void* Kh = nullptr;           // idem, rows permuted by pi inside each 32-key tile
+    void* Vt = nullptr;           // V transposed, fragment-major
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
 };
@@ -33,17 +33,18 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
                              const float* gamma, const float* beta, float eps, void* X, float* kbias,
                              int B, int S, int Sp, int H, int vocab, int pad_id);
 
-// Per batch row: klen[b] = 1 + last valid key (0 if none); ordered positions of class tokens
+// Per batch row: klen[b] = 1 + last valid key (0 if none), kfirst[b] = first masked key (S if none); ordered positions of class tokens
 // cls_pos[b*c_cap + j] (-1 beyond the row's count) and cls_cnt[b].
 const char* glc_launch_scan_rows(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int S,
-                                 int class_token, int embed_class_token, int* klen, int* cls_pos, int* cls_cnt, int c_cap);
+                                 int class_token, int embed_class_token, int* klen, int* kfirst, int* cls_pos, int* cls_cnt, int c_cap);
 
 struct AttnArgs {
     const void* Qh; const void* Kh; const void* Vt;   // as written by EPI_QKV (Q pre-scaled by 1/sqrt(3d))
-    const void* PK; const void* PQ;                   // [nh, P, 64] T: key_proj(rel), query_proj(rel)/sqrt(3d)
+    const void* PK; const void* PQ;                   // nh*P*64 T: key_proj(rel) (K layout), query_proj(rel)/sqrt(3d) (Q layout)
     const int32_t* dtab;                              // [2*Sp-1] clamp(bucket(q-k)+span)
     const float* kbias;                               // [B, Sp]
-    const int* klen;                                  // [B]
+    const int* klen;                                  // [B] 1 + last valid key
+    const int* kfirst;                                // [B] first masked key (S if none)
     void* CTX;                                        // [B*Sp, H] T
     int B, nh, Sp, H, P;
 };

@@ -85,26 +85,30 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // one block per batch row; ordered compaction of class-token positions by a block-wide scan
 __global__ __launch_bounds__(256) void scan_rows_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask, int S,
                                                         int class_token, int embed_class_token, int* __restrict__ klen,
-                                                        int* __restrict__ cls_pos, int* __restrict__ cls_cnt, int c_cap) {
+                                                        int* __restrict__ kfirst, int* __restrict__ cls_pos, int* __restrict__ cls_cnt, int c_cap) {
     __shared__ int cnt[256];
     __shared__ int last[256];
+    __shared__ int first[256];
     __shared__ int tot;
     const int b = blockIdx.x, t = threadIdx.x;
     const int per = (S + 255) / 256;
     const int lo = t * per, hi = min(S, lo + per);
-    int c = 0, lv = 0;
+    int c = 0, lv = 0, fz = S;
     for (int s = lo; s < hi; ++s) {
         c += ids[(size_t)b * S + s] == class_token;
         if (mask[(size_t)b * S + s] != 0) lv = s + 1;
+        else if (fz == S) fz = s;
     }
     cnt[t] = c;
     last[t] = lv;
+    first[t] = fz;
     __syncthreads();
     if (t == 0) {
-        int run = 0, mx = 0;
-        for (int i = 0; i < 256; ++i) { const int v = cnt[i]; cnt[i] = run; run += v; mx = max(mx, last[i]); }
+        int run = 0, mx = 0, mn = S;
+        for (int i = 0; i < 256; ++i) { const int v = cnt[i]; cnt[i] = run; run += v; mx = max(mx, last[i]); mn = min(mn, first[i]); }
         cls_cnt[b] = run;
         klen[b] = mx;
+        kfirst[b] = mn;
         tot = run;
     }
     __syncthreads();
@@ -202,9 +206,9 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
 }
 
 const char* glc_launch_scan_rows(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int S, int class_token,
-                                 int embed_class_token, int* klen, int* cls_pos, int* cls_cnt, int c_cap) {
-    if (B <= 0 || S <= 0 || c_cap <= 0 || !ids || !mask || !klen || !cls_pos || !cls_cnt) return "scan_rows: bad args";
-    hipLaunchKernelGGL(scan_rows_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, class_token, embed_class_token, klen, cls_pos,
+                                 int embed_class_token, int* klen, int* kfirst, int* cls_pos, int* cls_cnt, int c_cap) {
+    if (B <= 0 || S <= 0 || c_cap <= 0 || !ids || !mask || !klen || !kfirst || !cls_pos || !cls_cnt) return "scan_rows: bad args";
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(B), dim3(256), 0, st, ids, mask, S, class_token, embed_class_token, klen, kfirst, cls_pos,
                        cls_cnt, c_cap);
     return nullptr;
 }

@@ -140,7 +140,7 @@ bool upload_as(glc_engine* e, const float* src, size_t n, void* dst, float* stag
 
 bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     const glc_model_config& c = e->cfg;
-    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 128);
+    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 256);
     const size_t es = esize(e->dtype);
     if (Mpad > e->capM) {
         void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
@@ -189,7 +189,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
 bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, int C, float* d_logits) {
     const glc_model_config& c = e->cfg;
     const int H = c.hidden, I = c.inter, nh = c.heads;
-    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 128);
+    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 256);
     hipStream_t st = e->stream;
     const int dt = e->dtype;
     const size_t es = esize(dt);
@@ -212,19 +212,19 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
-        { Prof p(e, PC_QKV); KCHK(glc_launch_gemm(st, dt, EPI_QKV, g), false); }
+        { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
-        { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm(st, dt, EPI_RESID, o), false); }
+        { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false); }
         { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
-        { Prof p(e, PC_FFN1); KCHK(glc_launch_gemm(st, dt, EPI_GELU, f1), false); }
+        { Prof p(e, PC_FFN1); KCHK(glc_launch_gemm_auto(st, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm(st, dt, EPI_RESID, f2), false); }
+        { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false); }
         { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
         if (e->keep_hidden)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
@@ -325,7 +325,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         if (!e->eln_g || !e->eln_b) { fail(); break; }
 
         // R = LayerNorm(rel_embeddings) in fp32 (HF:595-599), then to T, padded to 128 rows
-        const int Ppad = round_up(P, 128);
+        const int Ppad = round_up(P, 256);
         float* rel_f32 = upload_f32(e, tensors[3], (size_t)P * H);
         float* rg = upload_f32(e, tensors[4], H); float* rb = upload_f32(e, tensors[5], H);
         float* Rf = (float*)dmalloc(e, (size_t)Ppad * H * sizeof(float));
@@ -368,7 +368,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             GemmArgs g;
             g.A = Rt; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = w.PQ; g.Kh = w.PK; g.Vt = vscratch;
             g.Mpad = Ppad; g.N = 3 * H; g.K = H; g.Mvalid = P; g.Sp = P; g.nh = nh; g.H = H;
-            const char* gm = glc_launch_gemm(e->stream, dtype, EPI_QKV, g);
+            const char* gm = glc_launch_gemm_auto(e->stream, dtype, EPI_QKV, g);
             if (gm) { set_err(gm); lok = false; }
         }
         if (!lok) { fail(); break; }

@@ -20,7 +20,14 @@ struct GemmArgs {
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
 };
-const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);
+const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
+bool glc_gemm256_supported(int dtype, const GemmArgs& a);
+const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a);    // 256x256 tile, 16-bit T
+// picks the 256x256 LDS-DMA kernel when the shape allows it, else the 128x128 one
+inline const char* glc_launch_gemm_auto(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
+    const bool qkv_ok = epi != EPI_QKV || a.H % 256 == 0;
+    return (glc_gemm256_supported(dtype, a) && qkv_ok) ? glc_launch_gemm256(st, dtype, epi, a) : glc_launch_gemm(st, dtype, epi, a);
+}
 
 // Row LayerNorm: Y[m,:] = LN(X[m,:]) * gamma + beta, rows [0, M).  X, Y element type T.
 const char* glc_launch_layernorm(hipStream_t st, int dtype, const void* X, void* Y, const float* gamma,

@@ -5,7 +5,8 @@
 //     delta(q-k) = clamp(bucket(q-k) + span, 0, 2 span - 1)
 //     score[q,k] = ( Q_q.K_k  +  Q_q.PK[delta(q-k)]  +  K_k.PQ[delta(q-k)] ) / sqrt(3 d)
 // (c2p: :315-324, p2c: :327-343 — the p2c gather index clamp(-bucket(k-q)+span) equals delta(q-k)).
-// 1/sqrt(3d) is folded into Wq at load time, so Q and PQ = query_proj(rel) arrive pre-scaled.
+// log2(e)/sqrt(3d) is folded into Wq at load time, so Q and PQ = query_proj(rel) arrive pre-scaled and
+// the scores are in log2 units (softmax = exp2).
 // Key padding (masked_fill(finfo.min), :256-257) is an additive per-key bias of -1e30; rows whose
 // query is padding are don't-care (they never feed a valid row).
 //
@@ -31,6 +32,7 @@
 
 namespace {
 
+constexpr float RESCALE_THR = 8.0f;   // log2 units
 constexpr int LROW = 68;  // floats per LDS band row (64 + 4 pad: 16-B aligned rows, odd multiple of 4 banks)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -45,9 +47,15 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int Sp = a.Sp;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
-    if (q0 >= Sp) return;                      // whole wave leaves; no workgroup barriers below
-    const int bh = blockIdx.y, b = bh / a.nh, hh = bh - b * a.nh;
+    // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin to the 8 XCDs, so give all
+    // query blocks of one (batch, head) the same id % 8 — they then share one L2 for that head's K / V^T
+    // (speed only; any placement is correct).
+    const int nqb = (Sp + 127) >> 7;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int bh = xcd + 8 * (jj / nqb);
+    const int q0 = ((jj % nqb) * 4 + wave) * 32;
+    if (bh >= a.B * a.nh || q0 >= Sp) return;  // whole wave leaves; no workgroup barriers below
+    const int b = bh / a.nh, hh = bh - b * a.nh;
 
     // fragment-major operands (glc_layout.h): one tile = 4 (or 2x2) units of 64 lanes x 16 B
     const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64 + lane * 8;
@@ -185,15 +193,21 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);
-        const float alpha = __expf(m - mnew);
-        m = mnew;
+        // Deferred rescale: scores are in log2 units; the reference exponent m only moves when some row's
+        // maximum outgrows it by more than RESCALE_THR (P then stays <= 2^THR, exact in fp32 sums and
+        // at unchanged relative precision in the 16-bit P operand).  Wave-uniform branch.
+        if (__builtin_amdgcn_ballot_w64(mx - m > RESCALE_THR) != 0ull) {
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
         float psum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { sv[i] = __expf(sv[i] - mnew); psum += sv[i]; }
-        l = l * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
+        l += psum;
 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
     mx = red[0];
     __syncthreads();
     float sum = 0.f;
-    for (int k = t; k < Sp; k += 256) { const float p = __expf(sc[k] - mx); sc[k] = p; sum += p; }
+    for (int k = t; k < Sp; k += 256) { const float p = __builtin_amdgcn_exp2f(sc[k] - mx); sc[k] = p; sum += p; }
     red[t] = sum;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
@@ -292,7 +306,8 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention: bad shape";
     if (impl == 2 && dtype == GLC_DT_F32) return "attention: the MFMA band kernel needs 16-bit operands";
     if (impl == 2) {
-        dim3 grid((a.Sp / 32 + 3) / 4, a.B * a.nh), block(256);
+        const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
+        dim3 grid(nqb * bh8), block(256);
         if (dtype == GLC_DT_BF16) hipLaunchKernelGGL(attn_band_kernel<bf16_t>, grid, block, 0, st, a);
         else hipLaunchKernelGGL(attn_band_kernel<f16_t>, grid, block, 0, st, a);
         return nullptr;

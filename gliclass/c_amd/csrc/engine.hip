@@ -336,7 +336,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         if (!m) m = glc_launch_convert(e->stream, dtype, Rf, Rt, (size_t)Ppad * H);
         if (m) { set_err(m); fail(); break; }
 
-        const float inv_scale = 1.0f / sqrtf((float)cfg->head_dim * 3.0f);   // HF:237-242, scale_factor = 3
+        // HF:237-242: scores / sqrt(d * 3); times log2(e) so that the attention kernels can use exp2 directly
+        const float inv_scale = 1.4426950408889634f / sqrtf((float)cfg->head_dim * 3.0f);
         std::vector<float> wq((size_t)H * H), bq(H), bqkv(3 * (size_t)H);
         e->layers.resize(L);
         bool lok = true;
@@ -350,7 +351,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             w.PK = dmalloc(e, (size_t)nh * P * 64 * es);
             w.PQ = dmalloc(e, (size_t)nh * P * 64 * es);
             if (!w.Wqkv || !w.Wo || !w.W1 || !w.W2 || !w.PK || !w.PQ) { lok = false; break; }
-            for (size_t i = 0; i < (size_t)H * H; ++i) wq[i] = t[0][i] * inv_scale;   // fold 1/sqrt(3d) into the query projection
+            for (size_t i = 0; i < (size_t)H * H; ++i) wq[i] = t[0][i] * inv_scale;   // fold log2(e)/sqrt(3d) into the query projection
             for (int i = 0; i < H; ++i) { bqkv[i] = t[1][i] * inv_scale; bqkv[H + i] = t[3][i]; bqkv[2 * H + i] = t[5][i]; }
             lok = upload_as(e, wq.data(), (size_t)H * H, w.Wqkv, staging) &&
                   upload_as(e, t[2], (size_t)H * H, (char*)w.Wqkv + (size_t)H * H * es, staging) &&
@@ -364,7 +365,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             w.ln2g = upload_f32(e, t[14], H); w.ln2b = upload_f32(e, t[15], H);
             if (!w.bqkv || !w.bo || !w.ln1g || !w.ln1b || !w.b1 || !w.b2 || !w.ln2g || !w.ln2b) { lok = false; break; }
             if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // bqkv host buffer is reused
-            // position projections (HF:296-302, share_att_key): PQ = query_proj(R)/sqrt(3d), PK = key_proj(R), [nh,P,64]
+            // position projections (HF:296-302, share_att_key): PQ = query_proj(R)*log2e/sqrt(3d), PK = key_proj(R)
             GemmArgs g;
             g.A = Rt; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = w.PQ; g.Kh = w.PK; g.Vt = vscratch;
             g.Mpad = Ppad; g.N = 3 * H; g.K = H; g.Mvalid = P; g.Sp = P; g.nh = nh; g.H = H;

@@ -1,0 +1,52 @@
+"""Summarise rocprofv3 CSVs written by scripts/profile_gpu.sh: per-kernel time (kernel-trace stats)
+and per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes.  gfx950 corrections per
+MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2;
+WRITE_SIZE is exact; both counters are in KiB."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"void ", "", n)
+    return n[:90]
+
+
+def find(pattern):
+    fs = glob.glob(os.path.join(out, pattern), recursive=True)
+    return fs[0] if fs else None
+
+
+st = find("trace/**/*kernel_stats.csv")
+if st:
+    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    rows = list(csv.DictReader(open(st)))
+    print("columns:", list(rows[0].keys()) if rows else None)
+    for r in rows[:16]:
+        name = r.get("Name") or r.get("KernelName") or ""
+        print(f'{short(name):92s} calls={r.get("Calls")} avg_us={float(r.get("AverageNs", 0))/1e3:9.1f} total_ms={float(r.get("TotalDurationNs", 0))/1e6:9.2f} pct={r.get("Percentage")}')
+
+for tag, corr in (("fetch", 2.0), ("write", 1.0)):
+    f = find(f"pmc_{tag}/**/*counter_collection.csv")
+    if not f:
+        print(f"no counter file for {tag}")
+        continue
+    acc = defaultdict(lambda: [0.0, 0])
+    cols = None
+    for r in csv.DictReader(open(f)):
+        cols = cols or list(r.keys())
+        name = r.get("Kernel_Name") or r.get("KernelName") or ""
+        val = float(r.get("Counter_Value") or 0)
+        a = acc[short(name)]
+        a[0] += val
+        a[1] += 1
+    print(f"== {tag.upper()}_SIZE per launch (KiB raw -> bytes x1024, gfx950 correction x{corr}) ==")
+    print("columns:", cols)
+    for name, (tot, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]:
+        print(f"{name:92s} launches={n:5d} avg_MB={tot / n * 1024 * corr / 1e6:10.2f}")

@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     float* c2p_l = lds + (size_t)wave * 2 * 32 * LROW;
     float* p2c_l = c2p_l + 32 * LROW;
 
-    const int pr = (c & 0x13) | ((c & 4) << 1) | ((c & 8) >> 1);   // pi(c)
     int nkt = (a.klen[b] + 31) >> 5;                               // key tiles beyond the last valid key add exactly 0
     nkt = nkt < 1 ? 1 : (nkt > (Sp >> 5) ? (Sp >> 5) : nkt);
     const int kfirst = a.kfirst[b];                                // first masked key: tiles below it need no key bias
@@ -158,12 +157,12 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) mma32(pq_lo[s], kf[s], bacc);
-            band_store(p2c_l + pr * LROW, bacc);
+            band_store(p2c_l + c * LROW, bacc);          // row = lane (conflict-free); the gather applies pi
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) mma32(pq_hi[s], kf[s], bacc);
-            band_store(p2c_l + pr * LROW + 32, bacc);
+            band_store(p2c_l + c * LROW + 32, bacc);
         }
         frag_t vt[2][2];
 #pragma unroll
@@ -178,8 +177,9 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kc = 16 * (i >> 3) + (i & 7);                         // key offset minus 8h
+            const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);  // pi(key offset) minus 4h: p2c rows are in lane order
             const int rr = rr_base - kc;
-            sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(kc + 8 * h) * LROW + rr];
+            sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(prow + 4 * h) * LROW + rr];
         }
         if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);

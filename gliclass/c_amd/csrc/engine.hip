@@ -517,6 +517,43 @@ int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems)
     return 0;
 }
 
+/* Developer microbenchmark: time `iters` launches of one GEMM shape on random 16-bit data (HIP events).
+ * which: 0 = auto (256-tile when possible), 1 = force the 128x128 kernel.  Returns ms per launch or <0. */
+float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which) {
+    if (!e || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || e->dtype == GLC_F32 || epi < EPI_BIAS || epi > EPI_RESID) { set_err("gemm_bench: bad args"); return -1.f; }
+    if (M % 256 || N % 256 || K % 64) { set_err("gemm_bench: M,N %256, K %64 required"); return -1.f; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1.f);
+    const size_t es = 2;
+    void *A = nullptr, *W = nullptr, *C = nullptr, *R = nullptr; float *bias = nullptr, *tmp = nullptr;
+    const size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
+    const size_t nmax = nA > nW ? (nA > nC ? nA : nC) : (nW > nC ? nW : nC);
+    float ms = -1.f;
+    do {
+        if (hipMalloc(&A, nA * es) || hipMalloc(&W, nW * es) || hipMalloc(&C, nC * es) || hipMalloc(&R, nC * es) ||
+            hipMalloc((void**)&bias, N * sizeof(float)) || hipMalloc((void**)&tmp, nmax * sizeof(float))) { set_err("gemm_bench: alloc failed"); break; }
+        std::vector<float> h(nmax);
+        unsigned s = 12345u;
+        for (size_t i = 0; i < nmax; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((float)(s >> 8) / 8388608.f - 1.f) * 0.5f; }
+        if (hipMemcpy(tmp, h.data(), nmax * sizeof(float), hipMemcpyHostToDevice)) { set_err("gemm_bench: copy failed"); break; }
+        if (glc_launch_convert(e->stream, e->dtype, tmp, A, nA) || glc_launch_convert(e->stream, e->dtype, tmp, W, nW) ||
+            glc_launch_convert(e->stream, e->dtype, tmp, R, nC)) { set_err("gemm_bench: convert failed"); break; }
+        if (hipMemcpyAsync(bias, tmp, N * sizeof(float), hipMemcpyDeviceToDevice, e->stream)) break;
+        GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K;
+        const char* m = nullptr;
+        for (int i = 0; i < 2 && !m; ++i) m = which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g);
+        if (m) { set_err(m); break; }
+        if (hipEventRecord(e->t0, e->stream)) break;
+        for (int i = 0; i < iters; ++i) { if (which == 1) glc_launch_gemm(e->stream, e->dtype, epi, g); else glc_launch_gemm_auto(e->stream, e->dtype, epi, g); }
+        if (hipEventRecord(e->t1, e->stream) || hipEventSynchronize(e->t1)) { set_err("gemm_bench: sync failed"); break; }
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e->t0, e->t1)) break;
+        ms = t / iters;
+    } while (0);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(R); (void)hipFree(bias); (void)hipFree(tmp);
+    return ms;
+}
+
 const glc_model_config* glc_engine_config(const glc_engine* e) { return e ? &e->cfg : nullptr; }
 int glc_engine_dtype(const glc_engine* e) { return e ? e->dtype : -1; }
 

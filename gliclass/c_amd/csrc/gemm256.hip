@@ -13,6 +13,7 @@
 //     s_waitcnt vmcnt(0) + s_barrier per K-tile;
 //   * workgroup ids are remapped so that the tiles of one XCD (blockIdx % 8) are consecutive in
 //     (m, n) order: the n-tiles of an A panel share one L2.
+#include <stdlib.h>
 #include "glc_common.h"
 #include "glc_kernels.h"
 #include "glc_layout.h"
@@ -22,6 +23,7 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int ROWB = 128;                  // bytes of K per row per stage (64 x 16-bit)
 constexpr int STAGE = (TM + TN) * ROWB;    // 64 KiB
+constexpr int EPI_PATCH = 9216;            // bytes of wave-private fp32 epilogue staging (8 x 9 KiB < 2 stages)
 extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
@@ -40,8 +42,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int n_tile0
     // XCD-aware tile order (bijective for any grid size)
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (tile / ntn) * TM, n0 = (n_tile0 + tile % ntn) * TN;   // this launch covers n-tiles [n_tile0, n_tile0 + ntn)
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    if (p.order == 1) tile = bid;                               // experiment: plain order
+    const int mt = tile / ntn, nt = tile % ntn;
+    const int m0 = mt * TM, n0 = (n_tile0 + nt) * TN;   // this launch covers n-tiles [n_tile0, n_tile0 + ntn)
 
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
@@ -111,57 +115,110 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int n_tile0
     }
 
     // ---------------- epilogue ----------------
+    // The accumulator layout gives a lane 4 consecutive columns of one row (8-byte pieces).  Storing that
+    // directly costs 32 narrow, scattered stores per lane — as much time as a K=768 main loop.  Instead each
+    // wave stages its 128x64 sub-tile through a PRIVATE fp32 LDS patch, 32 rows at a time (the stage ring
+    // is dead after the last barrier), and writes it back as 16-byte pieces: one wave instruction = 8 rows
+    // x 128 contiguous bytes (row-major outputs) or whole 16-byte fragment units (Q / K / V^T).  Bias and
+    // GELU are applied before staging, the residual is added in fp32 at the store, so the value is rounded
+    // once, exactly as before.  Wave-local LDS ordering only; no workgroup barrier.
+    typedef __attribute__((ext_vector_type(8))) T vec8T;
     const float* __restrict__ bias = p.bias;
+    float* stg = reinterpret_cast<float*>(smem256 + wave * EPI_PATCH);
     const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;
     if (!vmode) {
+        // D[n = 16j + 4g + r][m = 16i + r16]; patch [32 rows m][64 cols n], row stride 68 floats
+        const int which = (EPI == EPI_QKV) ? n0 / p.H : 0;
+        float bj[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * g;
-            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-            if (bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n); b0 = bv[0]; b1 = bv[1]; b2 = bv[2]; b3 = bv[3]; }
-            // QKV scatter: (which, head, dd) are uniform over i
-            const int which = (EPI == EPI_QKV) ? n0 / p.H : 0;
-            const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;
+            if (bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + j * 16 + 4 * g); bj[j][0] = bv[0]; bj[j][1] = bv[1]; bj[j][2] = bv[2]; bj[j][3] = bv[3]; }
+            else { bj[j][0] = bj[j][1] = bj[j][2] = bj[j][3] = 0.f; }
+        }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + wm * 128 + i * 16 + r16;
-                float v0 = acc[i][j][0] + b0, v1 = acc[i][j][1] + b1, v2 = acc[i][j][2] + b2, v3 = acc[i][j][3] + b3;
-                if (EPI == EPI_GELU) { v0 = glc_gelu(v0); v1 = glc_gelu(v1); v2 = glc_gelu(v2); v3 = glc_gelu(v3); }
-                if (EPI == EPI_RESID) {
-                    float r0, r1, r2, r3;
-                    load4<T>(reinterpret_cast<const T*>(p.resid) + (size_t)m * N + n, r0, r1, r2, r3);
-                    v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[2 * c + ii][j];
+                    v[0] += bj[j][0]; v[1] += bj[j][1]; v[2] += bj[j][2]; v[3] += bj[j][3];
+                    if (EPI == EPI_GELU) {
+                        const f32x2 g0 = glc_gelu2((f32x2){v[0], v[1]}), g1 = glc_gelu2((f32x2){v[2], v[3]});
+                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                    }
+                    *reinterpret_cast<f32x4*>(stg + (ii * 16 + r16) * 68 + j * 16 + 4 * g) = v;
                 }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int m = m0 + wm * 128 + c * 32 + row;
+                const int n = n0 + wn * 64 + g8 * 8;
+                if (EPI == EPI_RESID) {
+                    const vec8T r = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) + (size_t)m * N + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+                }
+                vec8T o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
                 if (EPI == EPI_QKV) {
                     if (m < p.Mvalid) {
-                        int b = qkv_b0, s = m - qkv_b0 * p.Sp;
-                        while (s >= p.Sp) { s -= p.Sp; ++b; }          // a 256-row tile spans <= 5 sequences (Sp >= 64)
+                        int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                        while (sq >= p.Sp) { sq -= p.Sp; ++b; }          // a 256-row tile spans <= 5 sequences (Sp >= 64)
+                        const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;     // dd is a multiple of 8: one 16-B unit
                         const int bh = b * p.nh + hh;
-                        T* dst = which == 0 ? reinterpret_cast<T*>(p.Qh) + glc_qoff(p.Sp, bh, s, dd)
-                                            : reinterpret_cast<T*>(p.Kh) + glc_koff(p.Sp, bh, s, dd);
-                        store4<T>(dst, v0, v1, v2, v3);
+                        T* dst = which == 0 ? reinterpret_cast<T*>(p.Qh) + glc_qoff(p.Sp, bh, sq, dd)
+                                            : reinterpret_cast<T*>(p.Kh) + glc_koff(p.Sp, bh, sq, dd);
+                        *reinterpret_cast<vec8T*>(dst) = o;
                     }
                 } else {
-                    store4<T>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n, v0, v1, v2, v3);
+                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n) = o;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     } else {
+        // V third: D[m = 16i + 4g + r][n = 16j + r16]; patch [64 rows dd][32 cols key], row stride 36 floats
+        float bn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + r16;
-            const float bv = bias ? bias[n] : 0.f;
-            const int nn = n - 2 * p.H, hh = nn >> 6, dd = nn & 63;
+        for (int j = 0; j < 4; ++j) bn[j] = bias ? bias[n0 + wn * 64 + j * 16 + r16] : 0.f;
+        const int hh = (n0 + wn * 64 - 2 * p.H) >> 6;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + wm * 128 + i * 16 + 4 * g;
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[2 * c + ii][j];
+                    v[0] += bn[j]; v[1] += bn[j]; v[2] += bn[j]; v[3] += bn[j];
+                    *reinterpret_cast<f32x4*>(stg + (j * 16 + r16) * 36 + ii * 16 + 4 * g) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, dd = idx >> 2, kg = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8 + 4);
+                vec8T o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (T)lo[e]; o[4 + e] = (T)hi[e]; }
+                const int m = m0 + wm * 128 + c * 32 + kg * 8;           // first of 8 consecutive keys
                 if (m < p.Mvalid) {
-                    int b = qkv_b0, s = m - qkv_b0 * p.Sp;
-                    while (s >= p.Sp) { s -= p.Sp; ++b; }
-                    T* dst = reinterpret_cast<T*>(p.Vt) + glc_voff(p.Sp, b * p.nh + hh, dd, s);
-                    store4<T>(dst, acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+                    int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                    while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + glc_voff(p.Sp, b * p.nh + hh, dd, sq)) = o;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -202,7 +259,10 @@ bool glc_gemm256_supported(int dtype, const GemmArgs& a) {
 
 // Host-side shape contract: 16-bit T; Mpad % 256 == 0 (buffers allocated with Mpad rows), N % 256 == 0,
 // K % 64 == 0; EPI_QKV: H % 256 == 0 (a tile never straddles Q|K|V), Sp % 64 == 0.
-const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
+const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a_in) {
+    GemmArgs a = a_in;
+    static const int env_order = getenv("GLC_GEMM_ORDER") ? atoi(getenv("GLC_GEMM_ORDER")) : 0;
+    a.order = env_order;
     if (!glc_gemm256_supported(dtype, a)) return "gemm256: unsupported shape";
     if (!a.A || !a.W) return "gemm256: null operand";
     if (epi == EPI_QKV) {

@@ -67,13 +67,35 @@ template <typename T> __device__ __forceinline__ void load4(const T* p, float& a
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. at fp32 resolution for GELU's use)
 __device__ __forceinline__ float glc_erf(float x) {
     float ax = fabsf(x);
-    float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
     float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     float r = 1.0f - p * __expf(-ax * ax);
     return copysignf(r, x);
 }
 // HF ACT2FN["gelu"]: 0.5 x (1 + erf(x / sqrt 2))   (modeling_deberta_v2.py:393-396)
 __device__ __forceinline__ float glc_gelu(float x) { return 0.5f * x * (1.0f + glc_erf(x * 0.70710678118654752f)); }
+
+// Packed GELU on two values at once: the polynomial part runs on v_pk_*_f32 (two lanes' worth per issue),
+// and GELU(x) = 0.5 (x + |x| erf(|x|/sqrt2)) needs no copysign.  Same Abramowitz-Stegun 7.1.26 erf as above.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 glc_gelu2(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 d = z * 0.3275911f + 1.0f;
+    f32x2 t;
+    t[0] = __builtin_amdgcn_rcpf(d[0]); t[1] = __builtin_amdgcn_rcpf(d[1]);
+    f32x2 pl = t * 1.061405429f + (-1.453152027f);
+    pl = pl * t + 1.421413741f;
+    pl = pl * t + (-0.284496736f);
+    pl = pl * t + 0.254829592f;
+    pl = pl * t;
+    const f32x2 w = ax * 0.84932180028801904f;            // sqrt(log2(e) / 2): exp(-z^2) = exp2(-w^2)
+    const f32x2 w2 = w * w;
+    f32x2 ex;
+    ex[0] = __builtin_amdgcn_exp2f(-w2[0]); ex[1] = __builtin_amdgcn_exp2f(-w2[1]);
+    const f32x2 y = 1.0f - pl * ex;                        // erf(|x|/sqrt2)
+    return (ax * y + x) * 0.5f;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -19,6 +19,7 @@ struct GemmArgs {
     void* Vt = nullptr;           // V transposed, fragment-major
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
+    int order = 0;                          // gemm256 tile-order experiment switch
 };
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);

@@ -243,31 +243,48 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     }
 }
 
-// Straightforward kernel (any T, no MFMA): one block per (query, batch*head).  fp32 path and the
-// on-device cross-check of the band kernel.
+// Straightforward kernel (any T, no MFMA): one block per (query row, batch*head).  Serves the fp32 mode, the
+// on-device cross-check of the band kernel, and — with a row selection — the pruned last layer, where only
+// the 1+C rows per sequence that the head reads need attention output (their positions are arbitrary, so
+// the 32-consecutive-query band kernel does not apply).  16-byte loads in the fragment-major layouts.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
+    constexpr int VEC = 16 / (int)sizeof(T);          // elements per 16-byte chunk (8, or 4 for f32)
+    typedef __attribute__((ext_vector_type(VEC))) T vecT;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* qv = sm;            // [64]
     float* red = sm + 64;      // [256]
     float* sc = sm + 64 + 256; // [Sp]
-    const int Sp = a.Sp, q = blockIdx.x, bh = blockIdx.y, b = bh / a.nh, hh = bh - b * a.nh;
-    const int t = threadIdx.x;
-    const T* Qg = reinterpret_cast<const T*>(a.Qh);
+    const int Sp = a.Sp, hh = blockIdx.y, t = threadIdx.x;
+    int b, q, orow;
+    if (a.sel_b) { b = a.sel_b[blockIdx.x]; q = a.sel_q[blockIdx.x]; orow = blockIdx.x; }
+    else { b = blockIdx.z; q = blockIdx.x; orow = b * Sp + q; }
+    const int bh = b * a.nh + hh;
     const T* Kg = reinterpret_cast<const T*>(a.Kh);
     const T* Vg = reinterpret_cast<const T*>(a.Vt);
     const T* PKg = reinterpret_cast<const T*>(a.PK);
     const T* PQg = reinterpret_cast<const T*>(a.PQ);
     const float* kb = a.kbias + (size_t)b * Sp;
-    if (t < 64) qv[t] = (float)Qg[glc_qoff(Sp, bh, q, t)];
+    if (t < 64)
+        qv[t] = a.Qrow ? (float)reinterpret_cast<const T*>(a.Qrow)[(size_t)orow * a.H + hh * 64 + t]
+                       : (float)reinterpret_cast<const T*>(a.Qh)[glc_qoff(Sp, bh, q, t)];
     __syncthreads();
+    int kend = (a.klen[b] + 7) & ~7;                  // keys past the last valid one contribute exactly 0
+    kend = kend < 8 ? 8 : (kend > Sp ? Sp : kend);
     float mx = -3.0e38f;
-    for (int k = t; k < Sp; k += 256) {
+    for (int k = t; k < kend; k += 256) {
         const int dl = a.dtab[q - k + Sp - 1];
         float s = 0.f;
-        for (int e = 0; e < 64; ++e) {
-            const float kv = (float)Kg[glc_koff(Sp, bh, k, e)];
-            s += qv[e] * (kv + (float)PKg[glc_koff(a.P, hh, dl, e)]) + kv * (float)PQg[glc_qoff(a.P, hh, dl, e)];
+#pragma unroll
+        for (int e0 = 0; e0 < 64; e0 += VEC) {
+            const vecT kv = *reinterpret_cast<const vecT*>(Kg + glc_koff(Sp, bh, k, e0));
+            const vecT pk = *reinterpret_cast<const vecT*>(PKg + glc_koff(a.P, hh, dl, e0));
+            const vecT pq = *reinterpret_cast<const vecT*>(PQg + glc_qoff(a.P, hh, dl, e0));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float kf = (float)kv[e];
+                s += qv[e0 + e] * (kf + (float)pk[e]) + kf * (float)pq[e];
+            }
         }
         s += kb[k];
         sc[k] = s;
@@ -279,21 +296,24 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
     mx = red[0];
     __syncthreads();
     float sum = 0.f;
-    for (int k = t; k < Sp; k += 256) { const float p = __builtin_amdgcn_exp2f(sc[k] - mx); sc[k] = p; sum += p; }
+    for (int k = t; k < kend; k += 256) { const float p = __builtin_amdgcn_exp2f(sc[k] - mx); sc[k] = p; sum += p; }
     red[t] = sum;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
     const float inv = 1.0f / red[0];
     __syncthreads();
     const int dd = t & 63, part = t >> 6;
-    const int per = (Sp + 3) / 4, klo = part * per, khi = min(Sp, klo + per);
     float acc = 0.f;
-    for (int k = klo; k < khi; ++k) acc += sc[k] * (float)Vg[glc_voff(Sp, bh, dd, k)];
+    for (int k0 = part * VEC; k0 < kend; k0 += 4 * VEC) {            // 16-byte units of V^T: VEC consecutive keys
+        const vecT vv = *reinterpret_cast<const vecT*>(Vg + glc_voff(Sp, bh, dd, k0));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc += sc[k0 + e] * (float)vv[e];
+    }
     red[t] = acc;
     __syncthreads();
     if (t < 64) {
         const float v = (red[t] + red[t + 64] + red[t + 128] + red[t + 192]) * inv;
-        reinterpret_cast<T*>(a.CTX)[((size_t)b * Sp + q) * a.H + hh * 64 + t] = (T)v;
+        reinterpret_cast<T*>(a.CTX)[(size_t)orow * a.H + hh * 64 + t] = (T)v;
     }
 }
 
@@ -302,9 +322,10 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
 // Shape contract: head_dim == 64, Sp % 64 == 0, P % 32 == 0, H == nh*64, dtab has 2*Sp-1 entries in [0, P);
 // Q/K/V^T/PQ/PK in the fragment-major layouts of glc_layout.h.
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a) {
-    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.kfirst || !a.CTX) return "attention: null pointer";
+    if ((!a.Qh && !a.Qrow) || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.kfirst || !a.CTX) return "attention: null pointer";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention: bad shape";
     if (impl == 2 && dtype == GLC_DT_F32) return "attention: the MFMA band kernel needs 16-bit operands";
+    if (impl == 2 && (a.sel_b || !a.Qh)) return "attention: the band kernel takes no row selection";
     if (impl == 2) {
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
@@ -314,7 +335,8 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     }
     const size_t shm = (size_t)(64 + 256 + a.Sp) * sizeof(float);
     if (shm > 64 * 1024) return "attention(simple): sequence too long for the reference kernel";
-    dim3 grid(a.Sp, a.B * a.nh), block(256);
+    if ((a.sel_b != nullptr) != (a.sel_q != nullptr) || (a.sel_b && (!a.Qrow || a.nsel <= 0))) return "attention(simple): bad row selection";
+    dim3 grid(a.sel_b ? a.nsel : a.Sp, a.nh, a.sel_b ? 1 : a.B), block(256);
     switch (dtype) {
         case GLC_DT_F32: hipLaunchKernelGGL(attn_simple_kernel<float>, grid, block, shm, st, a); break;
         case GLC_DT_BF16: hipLaunchKernelGGL(attn_simple_kernel<bf16_t>, grid, block, shm, st, a); break;

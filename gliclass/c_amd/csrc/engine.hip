@@ -39,9 +39,9 @@ void set_err(const std::string& s) { g_err = s; }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t esize(int dtype) { return dtype == GLC_F32 ? 4 : 2; }
 
-enum { PC_SCAN = 0, PC_EMBED, PC_QKV, PC_ATTN, PC_ATTN_OUT, PC_LN, PC_FFN1, PC_FFN2, PC_HEAD, PC_N };
+enum { PC_SCAN = 0, PC_EMBED, PC_QKV, PC_ATTN, PC_ATTN_OUT, PC_LN, PC_FFN1, PC_FFN2, PC_HEAD, PC_LAST, PC_N };
 const char* const kProfNames[PC_N] = {"scan_rows", "embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm",
-                                      "gemm_ffn1_gelu", "gemm_ffn2", "head"};
+                                      "gemm_ffn1_gelu", "gemm_ffn2", "head", "last_layer_pruned"};
 
 struct LayerW {
     void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;       // T
@@ -55,6 +55,7 @@ struct LayerW {
 struct glc_engine {
     glc_model_config cfg{};
     int dtype = GLC_F32, device = 0, attn_impl = 0;
+    bool prune_last = true;         // last layer only on the rows the head reads (exact)
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::vector<void*> allocs;      // everything freed at destroy
@@ -64,7 +65,9 @@ struct glc_engine {
     float* headw[8] = {nullptr};
     int P = 0;
     // workspace
-    int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0;
+    int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0, capSel = 0;
+    void *Xs = nullptr, *Qs = nullptr, *CTXs = nullptr, *T1s = nullptr, *H1s = nullptr, *FFs = nullptr;   // compact rows of the pruned last layer
+    int *sel_b = nullptr, *sel_q = nullptr;
     void *X = nullptr, *Qh = nullptr, *Kh = nullptr, *Vt = nullptr, *CTX = nullptr, *T1 = nullptr, *H1 = nullptr, *FF = nullptr;
     float* kbias = nullptr; int *klen = nullptr, *kfirst = nullptr, *cls_pos = nullptr, *cls_cnt = nullptr;
     int64_t *d_ids = nullptr, *d_mask = nullptr;
@@ -174,6 +177,16 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         for (float** b : bufs) { dfree(e, *b); *b = (float*)dmalloc(e, (size_t)hr * c.hidden * sizeof(float)); if (!*b) return false; }
         e->capHeadRows = hr;
     }
+    const int rsel = round_up(B * (1 + (C > 0 ? C : 0)), 256);
+    if (rsel > e->capSel) {
+        void** bufs[] = {&e->Xs, &e->Qs, &e->CTXs, &e->T1s, &e->H1s};
+        for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)rsel * c.hidden * es); if (!*b) return false; }
+        dfree(e, e->FFs); e->FFs = dmalloc(e, (size_t)rsel * c.inter * es); if (!e->FFs) return false;
+        dfree(e, e->sel_b); dfree(e, e->sel_q);
+        e->sel_b = (int*)dmalloc(e, (size_t)rsel * sizeof(int)); e->sel_q = (int*)dmalloc(e, (size_t)rsel * sizeof(int));
+        if (!e->sel_b || !e->sel_q) return false;
+        e->capSel = rsel;
+    }
     if (!e->dtabs.count(Sp)) {
         std::vector<int32_t> t(2 * Sp - 1);
         glc_delta_table(Sp, c.pos_buckets, c.max_rel_pos, t.data());
@@ -207,11 +220,14 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
 
     const int impl = e->attn_impl ? e->attn_impl : (dt == GLC_F32 ? 1 : 2);
+    const bool prune = e->prune_last && !e->keep_hidden && c.pooling == GLC_POOL_FIRST;
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
+        const bool last = prune && l == c.layers - 1;
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
+        if (last) break;
         { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
@@ -229,9 +245,41 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         if (e->keep_hidden)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     }
+    const int Cc = C > 0 ? C : 0;
+    if (prune) {
+        // Last layer, exact pruning: the head reads only the [CLS] row and the class-token rows, so only those
+        // R = B*(1+C) rows need Q, attention output, the output projection and the FFN.  K and V^T are still
+        // produced for every position (they are what the selected queries attend to).
+        Prof p(e, PC_LAST);
+        const LayerW& w = e->layers[c.layers - 1];
+        const int R = B * (1 + Cc), Rpad = round_up(R, 256);
+        GemmArgs g;
+        g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = 1;
+        g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
+        KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false);
+        KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, B, Sp, H, Cc), false);
+        GemmArgs gq;     // Q rows of the selection: the first H rows of the fused [3H,H] weight are the (pre-scaled) query projection
+        gq.A = e->Xs; gq.W = w.Wqkv; gq.bias = w.bqkv; gq.C = e->Qs; gq.Mpad = Rpad; gq.N = H; gq.K = H;
+        KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, gq), false);
+        AttnArgs a{nullptr, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTXs, B, nh, Sp, H, e->P};
+        a.sel_b = e->sel_b; a.sel_q = e->sel_q; a.Qrow = e->Qs; a.nsel = R;
+        KCHK(glc_launch_attention(st, dt, 1, a), false);
+        GemmArgs o;
+        o.A = e->CTXs; o.W = w.Wo; o.bias = w.bo; o.C = e->T1s; o.resid = e->Xs; o.Mpad = Rpad; o.N = H; o.K = H;
+        KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false);
+        KCHK(glc_launch_layernorm(st, dt, e->T1s, e->H1s, w.ln1g, w.ln1b, c.ln_eps, R, H), false);
+        GemmArgs f1;
+        f1.A = e->H1s; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FFs; f1.Mpad = Rpad; f1.N = I; f1.K = H;
+        KCHK(glc_launch_gemm_auto(st, dt, EPI_GELU, f1), false);
+        GemmArgs f2;
+        f2.A = e->FFs; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1s; f2.resid = e->H1s; f2.Mpad = Rpad; f2.N = H; f2.K = I;
+        KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false);
+        KCHK(glc_launch_layernorm(st, dt, e->T1s, e->Xs, w.ln2g, w.ln2b, c.ln_eps, R, H), false);
+    }
     if (C > 0) {
         Prof p(e, PC_HEAD);
-        KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, e->Gc, B, Sp, H, C), false);
+        if (prune) KCHK(glc_launch_head_gather_sel(st, dt, e->Xs, e->cls_pos, ccap, e->Gt, e->Gc, B, H, C), false);
+        else KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, e->Gc, B, Sp, H, C), false);
         const int rt = round_up(B, 128), rc = round_up(B * C, 128);
         GemmArgs h;
         h.N = H; h.K = H;
@@ -303,6 +351,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
 
     glc_engine* e = new glc_engine();
     e->cfg = *cfg; e->dtype = dtype; e->device = device;
+    if (const char* pv = getenv("GLICLASS_PRUNE_LAST")) e->prune_last = atoi(pv) != 0;
     const int H = cfg->hidden, I = cfg->inter, L = cfg->layers, nh = cfg->heads;
     const int span = cfg->pos_buckets > 0 ? cfg->pos_buckets : cfg->max_rel_pos;
     const int P = 2 * span;
@@ -491,6 +540,7 @@ int glc_profile_read(glc_engine* e, const char** names, float* total_ms, int* la
 }
 
 int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hidden = on != 0; return 0; }
+int glc_engine_set_prune_last_layer(glc_engine* e, int on) { if (!e) return -1; e->prune_last = on != 0; return 0; }
 int glc_debug_set_attention_impl(glc_engine* e, int impl) {
     if (!e || impl < 0 || impl > 2) { set_err("bad attention impl"); return -1; }
     if (impl == 2 && e->dtype == GLC_F32) { set_err("MFMA attention needs 16-bit operands"); return -1; }

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM, n0 = (blockIdx.x + ((EPI == EPI_QKV && p.qkv_skip_q) ? p.H / BN : 0)) * BN;
     const int K = p.K, N = p.N;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 }
 
 template <typename T> void launch_t(hipStream_t st, int epi, const GemmArgs& a) {
-    dim3 grid(a.N / BN, a.Mpad / BM), block(256);
+    const int nskip = (epi == EPI_QKV && a.qkv_skip_q) ? a.H / BN : 0;   // pruned last layer: K and V^T columns only
+    dim3 grid(a.N / BN - nskip, a.Mpad / BM), block(256);
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, a); break;
         case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU>), grid, block, 0, st, a); break;

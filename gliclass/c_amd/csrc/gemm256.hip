@@ -242,8 +242,8 @@ template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmAr
         case EPI_GELU: return launch_e<T, EPI_GELU, false>(st, a, 0, ntn);
         case EPI_RESID: return launch_e<T, EPI_RESID, false>(st, a, 0, ntn);
         case EPI_QKV: {   // Q|K columns in row orientation, V columns transposed: two grids, one stream
-            const int nqk = 2 * a.H / TN;
-            const char* m = launch_e<T, EPI_QKV, false>(st, a, 0, nqk);
+            const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;     // skip the Q columns when asked
+            const char* m = launch_e<T, EPI_QKV, false>(st, a, nq, nqk - nq);
             return m ? m : launch_e<T, EPI_QKV, true>(st, a, nqk, ntn - nqk);
         }
     }

@@ -20,6 +20,7 @@ struct GemmArgs {
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
     int order = 0;                          // gemm256 tile-order experiment switch
+    int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
 };
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);
@@ -53,8 +54,11 @@ struct AttnArgs {
     const float* kbias;                               // [B, Sp]
     const int* klen;                                  // [B] 1 + last valid key
     const int* kfirst;                                // [B] first masked key (S if none)
-    void* CTX;                                        // [B*Sp, H] T
+    void* CTX;                                        // [B*Sp, H] T  (or [nsel, H] with a row selection)
     int B, nh, Sp, H, P;
+    // optional row selection (simple kernel only): query r is row sel_q[r] of sequence sel_b[r]; its projected
+    // query is row r of the row-major Qrow [nsel, H]; output row r of CTX
+    const int* sel_b = nullptr; const int* sel_q = nullptr; const void* Qrow = nullptr; int nsel = 0;
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
@@ -65,6 +69,14 @@ const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, con
 // logits[b*C+j] = <Tt[b], Cc[b*C+j]> (* logit_scale when normalised)
 const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* Cc, float* logits, int B, int C, int H,
                                   int normalize, float logit_scale);
+
+// Pruned last layer: compact the rows the head reads. Row r < B: [CLS] of sequence r; row B + b*C + j: class
+// token j of sequence b (sequence start if absent). Writes Xs[r,:] = X[row,:] and the (sequence, position) lists.
+const char* glc_launch_gather_rows(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap, void* Xs,
+                                   int* sel_b, int* sel_q, int B, int Sp, int H, int C);
+// Head gather from the compact rows: Gt[b] = Xs[b]; Gc[b*C+j] = Xs[B+b*C+j] or 0 when the class token is absent.
+const char* glc_launch_head_gather_sel(hipStream_t st, int dtype, const void* Xs, const int* cls_pos, int c_cap,
+                                       float* Gt, float* Gc, int B, int H, int C);
 
 // dtype conversion fp32 -> T (weights upload), n elements
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);

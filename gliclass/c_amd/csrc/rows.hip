@@ -141,6 +141,44 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ 
     for (int i = lane; i < H; i += 64) dst[i] = src >= 0 ? (float)X[(size_t)src * H + i] : 0.f;
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
+                                                          T* __restrict__ Xs, int* __restrict__ sel_b, int* __restrict__ sel_q,
+                                                          int B, int Sp, int H, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * (1 + C)) return;
+    const int lane = threadIdx.x & 63;
+    int b = r, pos = 0;
+    if (r >= B) {
+        const int rr = r - B, j = rr % C;
+        b = rr / C;
+        pos = j < c_cap ? cls_pos[(size_t)b * c_cap + j] : -1;
+        if (pos < 0) pos = 0;
+    }
+    if (lane == 0) { sel_b[r] = b; sel_q[r] = pos; }
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef __attribute__((ext_vector_type(VEC))) T vecT;
+    const T* src = X + ((size_t)b * Sp + pos) * H;
+    for (int i = lane; i < H / VEC; i += 64) reinterpret_cast<vecT*>(Xs + (size_t)r * H)[i] = reinterpret_cast<const vecT*>(src)[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_gather_sel_kernel(const T* __restrict__ Xs, const int* __restrict__ cls_pos, int c_cap,
+                                                              float* __restrict__ Gt, float* __restrict__ Gc, int B, int H, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * (1 + C)) return;
+    const int lane = threadIdx.x & 63;
+    bool valid = true;
+    float* dst;
+    if (r < B) dst = Gt + (size_t)r * H;
+    else {
+        const int rr = r - B, b = rr / C, j = rr - b * C;
+        valid = j < c_cap && cls_pos[(size_t)b * c_cap + j] >= 0;
+        dst = Gc + (size_t)rr * H;
+    }
+    for (int i = lane; i < H; i += 64) dst[i] = valid ? (float)Xs[(size_t)r * H + i] : 0.f;
+}
+
 // logits[b*C + j] = <Tt[b], Cc[b*C+j]>   (gliclass scorer 'simple': einsum('BD,BCD->BC'))
 __global__ __launch_bounds__(256) void head_score_kernel(const float* __restrict__ Tt, const float* __restrict__ Cc,
                                                          float* __restrict__ logits, int B, int C, int H, int normalize,
@@ -219,6 +257,26 @@ const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, con
     const int rows = B * (1 + C);
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(head_gather_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, Gt, Gc, B, Sp, H, C);
+    });
+    return nullptr;
+}
+
+const char* glc_launch_gather_rows(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap, void* Xs, int* sel_b,
+                                   int* sel_q, int B, int Sp, int H, int C) {
+    if (B <= 0 || C < 0 || !X || !cls_pos || !Xs || !sel_b || !sel_q || H % 8) return "gather_rows: bad args";
+    const int rows = B * (1 + C);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, (T*)Xs, sel_b, sel_q, B, Sp, H, C);
+    });
+    return nullptr;
+}
+
+const char* glc_launch_head_gather_sel(hipStream_t st, int dtype, const void* Xs, const int* cls_pos, int c_cap, float* Gt, float* Gc,
+                                       int B, int H, int C) {
+    if (B <= 0 || C < 0 || !Xs || !cls_pos || !Gt || !Gc) return "head_gather_sel: bad args";
+    const int rows = B * (1 + C);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL(head_gather_sel_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)Xs, cls_pos, c_cap, Gt, Gc, B, H, C);
     });
     return nullptr;
 }

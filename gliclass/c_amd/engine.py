@@ -67,6 +67,9 @@ class Engine:
             raise self._err("glc_debug_get_hidden")
         return out
 
+    def set_prune_last_layer(self, on=True):
+        self.L.glc_engine_set_prune_last_layer(self.h, int(on))
+
     def keep_hidden(self, on=True):
         self.L.glc_debug_keep_hidden(self.h, int(on))
 

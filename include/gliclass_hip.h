@@ -76,6 +76,10 @@ int glc_engine_forward_device(glc_engine* e, const void* d_ids, const void* d_ma
                               void* d_logits);
 int glc_engine_sync(glc_engine* e);
 
+/* Exact last-layer pruning (default on; env GLICLASS_PRUNE_LAST=0 disables): the final encoder layer computes
+ * Q / attention output / FFN only for the rows the head reads ([CLS] + class tokens).  Logits are unchanged. */
+int glc_engine_set_prune_last_layer(glc_engine* e, int on);
+
 /* Device memory helpers so a host language can stage buffers without linking HIP itself. */
 void* glc_device_malloc(glc_engine* e, size_t bytes);
 void glc_device_free(glc_engine* e, void* p);

@@ -36,5 +36,9 @@ for dt in ("f32", "f16", "bf16"):
                 valid = mask[:, pos][:, :hs.shape[2]].astype(bool)
                 errs.append(float(np.abs(got[valid] - hs[wl][valid]).max()))
             dl = np.abs(lg - g["logits"]).max(); dp = np.abs(sig(lg) - g["probs"]).max()
-            print(f"[{dt} attn={impl}] {os.path.basename(p):24s} logit_err {dl:.2e} prob_err {dp:.2e} hidden_err {['%.1e'%x for x in errs]} finite={np.isfinite(lg).all()}", flush=True)
+            e.keep_hidden(False)
+            lgp = e.forward(ids, mask)   # pruned last layer path (default)
+            e.keep_hidden(True)
+            dpp = np.abs(sig(lgp) - g["probs"]).max()
+            print(f"[{dt} attn={impl}] {os.path.basename(p):24s} pruned_prob_err {dpp:.2e} logit_err {dl:.2e} prob_err {dp:.2e} hidden_err {['%.1e'%x for x in errs]} finite={np.isfinite(lg).all()}", flush=True)
     for e in eng.values(): e.close()

@@ -102,84 +102,20 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     frag_t qf[4];
     load_tile(Qp, 0, qf);
 
-    // ---- prologue: c2p blocks L(-1) -> ring half 1 and L(0) -> ring half 0; PQ fragments of both; K of tile 0 ----
-    frag_t kf[4], pq_lo[4], pq_hi[4];
-    {
-        frag_t pk[4];
-        f32x16 bacc;
-        int d = block_delta(-1);
-        load_pk(d, pk);
-        load_pq(d, pq_hi);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
-        band_store(c2p_l + c * LROW + 32, bacc);
-        d = block_delta(0);
-        load_pk(d, pk);
-        load_pq(d, pq_lo);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
-        band_store(c2p_l + c * LROW, bacc);
-        load_tile(Kp, 0, kf);
-    }
-    int d_next = block_delta(nkt > 1 ? 1 : 0);
-
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m = -3.0e38f, l = 0.f;
     const int rr_base = c - 8 * h + 31;
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V.
+    auto softmax_pv = [&](float (&sv)[16], int kt) {
         const int k0 = kt * 32;
-        // ---- prefetch the next tile's operands (clamped re-load on the last tile) ----
-        const int ktn = kt + 1 < nkt ? kt + 1 : kt;
-        frag_t n_kf[4], n_pq[4], pk[4];
-        load_tile(Kp, ktn, n_kf);
-        load_pq(d_next, n_pq);
-        load_pk(d_next, pk);
-        d_next = block_delta(kt + 2 < nkt ? kt + 2 : ktn);
-
-        // ---- S^T = K Q^T ; reg i <-> key k0 + 16*(i>>3) + 8h + (i&7) ----
-        f32x16 sacc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
-
-        // ---- p2c band for both blocks of this key tile: [rr][key pi(c)] ----
-        {
-            f32x16 bacc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pq_lo[s], kf[s], bacc);
-            band_store(p2c_l + c * LROW, bacc);          // row = lane (conflict-free); the gather applies pi
-#pragma unroll
-            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pq_hi[s], kf[s], bacc);
-            band_store(p2c_l + c * LROW + 32, bacc);
-        }
         frag_t vt[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             vt[0][t] = *reinterpret_cast<const frag_t*>(Vp + (size_t)kt * 2048 + t * 512);
             vt[1][t] = *reinterpret_cast<const frag_t*>(Vp + (size_t)kt * 2048 + 1024 + t * 512);
-        }
-        wave_lds_sync();
-
-        const int xr = (kt & 1) << 5;           // ring half that holds this tile's low block
-        float sv[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kc = 16 * (i >> 3) + (i & 7);                         // key offset minus 8h
-            const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);  // pi(key offset) minus 4h: p2c rows are in lane order
-            const int rr = rr_base - kc;
-            sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(prow + 4 * h) * LROW + rr];
         }
         if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
@@ -208,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
         l += psum;
-
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             frag_t pfr;
@@ -217,6 +152,125 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             mma32(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
             mma32(vt[1][t], pfr, o1);     //                   dd + 32
         }
+    };
+
+    // Saturated key tiles: every q-k of the tile lies beyond the clamp of the bucket table, so delta is ONE
+    // value d*: c2p = Q_q.PK[d*] is a per-query constant and p2c = K_k.PQ[d*] is a second product on the
+    // same K fragments.  8 + 4 MFMA, no band, no LDS.  (same operands, same fp32 accumulation as the band path)
+    auto sat_tiles = [&](int kt_lo, int kt_hi, int dstar) {
+        if (kt_lo >= kt_hi) return;
+        frag_t pqb[4], pkb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // broadcast fragments: every row / column is table row d*
+            pqb[s] = *reinterpret_cast<const frag_t*>(PQp + (size_t)(dstar >> 5) * 2048 + (dstar & 31) * 8 + s * 512);
+            pkb[s] = *reinterpret_cast<const frag_t*>(PKp + (size_t)(dstar >> 5) * 2048 + glc_pi32(dstar & 31) * 8 + s * 512);
+        }
+        float cq;
+        {
+            f32x16 t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pkb[s], qf[s], t);            // every row = PK[d*] . Q_c
+            cq = t[0];
+        }
+        frag_t kf[4];
+        load_tile(Kp, kt_lo, kf);
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            frag_t n_kf[4];
+            load_tile(Kp, kt + 1 < kt_hi ? kt + 1 : kt, n_kf);
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = cq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(kf[s], pqb[s], sacc);        // + K_k . PQ[d*] (same for every query column)
+            float sv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
+            softmax_pv(sv, kt);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = n_kf[s];
+        }
+    };
+
+    // key-tile ranges: [0, kt_a) saturated high (q-k >= rsat_pos), [kt_a, kt_b) banded, [kt_b, nkt) saturated low
+    int kt_a = q0 - 31 - a.rsat_pos >= 0 ? (q0 - 31 - a.rsat_pos) / 32 + 1 : 0;
+    kt_a = kt_a > nkt ? nkt : kt_a;
+    int kt_b = (q0 + 31 - a.rsat_neg + 31) / 32;
+    kt_b = kt_b < kt_a ? kt_a : (kt_b > nkt ? nkt : kt_b);
+
+    sat_tiles(0, kt_a, a.P - 1);
+
+    if (kt_a < kt_b) {
+    // ---- band prologue: c2p blocks L(kt_a-1), L(kt_a) -> their ring halves; PQ fragments of both; K of tile kt_a ----
+    frag_t kf[4], pq_lo[4], pq_hi[4];
+    {
+        frag_t pk[4];
+        f32x16 bacc;
+        int d = block_delta(kt_a - 1);
+        load_pk(d, pk);
+        load_pq(d, pq_hi);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+        band_store(c2p_l + c * LROW + (((kt_a - 1) & 1) << 5), bacc);
+        d = block_delta(kt_a);
+        load_pk(d, pk);
+        load_pq(d, pq_lo);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+        band_store(c2p_l + c * LROW + ((kt_a & 1) << 5), bacc);
+        load_tile(Kp, kt_a, kf);
+    }
+    int d_next = block_delta(kt_a + 1 < kt_b ? kt_a + 1 : kt_a);
+
+    for (int kt = kt_a; kt < kt_b; ++kt) {
+        // ---- prefetch the next tile's operands (clamped re-load on the last tile) ----
+        const int ktn = kt + 1 < kt_b ? kt + 1 : kt;
+        frag_t n_kf[4], n_pq[4], pk[4];
+        load_tile(Kp, ktn, n_kf);
+        load_pq(d_next, n_pq);
+        load_pk(d_next, pk);
+        d_next = block_delta(kt + 2 < kt_b ? kt + 2 : ktn);
+
+        // ---- S^T = K Q^T ; reg i <-> key k0 + 16*(i>>3) + 8h + (i&7) ----
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+
+        // ---- p2c band for both blocks of this key tile: [rr][key lane] ----
+        {
+            f32x16 bacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pq_lo[s], kf[s], bacc);
+            band_store(p2c_l + c * LROW, bacc);          // row = lane (conflict-free); the gather applies pi
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pq_hi[s], kf[s], bacc);
+            band_store(p2c_l + c * LROW + 32, bacc);
+        }
+        wave_lds_sync();
+
+        const int xr = (kt & 1) << 5;           // ring half that holds this tile's low block
+        float sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kc = 16 * (i >> 3) + (i & 7);                         // key offset minus 8h
+            const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);  // pi(key offset) minus 4h: p2c rows are in lane order
+            const int rr = rr_base - kc;
+            sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(prow + 4 * h) * LROW + rr];
+        }
+        softmax_pv(sv, kt);
 
         // ---- c2p band of the NEXT tile's low block L(kt+1) -> ring half (kt+1)&1 (held L(kt-1), now dead) ----
         {
@@ -232,6 +286,9 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) { pq_hi[s] = pq_lo[s]; pq_lo[s] = n_pq[s]; kf[s] = n_kf[s]; }
     }
+    }
+
+    sat_tiles(kt_b, nkt, 0);
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;

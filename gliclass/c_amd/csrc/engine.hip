@@ -73,6 +73,7 @@ struct glc_engine {
     int64_t *d_ids = nullptr, *d_mask = nullptr;
     float *Gt = nullptr, *Gc = nullptr, *G1t = nullptr, *G1c = nullptr, *G2t = nullptr, *G2c = nullptr, *d_logits = nullptr;
     std::map<int, int32_t*> dtabs;
+    std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
     // last forward
     int lastB = 0, lastS = 0, lastSp = 0;
     // debug
@@ -194,6 +195,11 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         if (!d) return false;
         if (hipMemcpy(d, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { set_err("dtab upload failed"); return false; }
         e->dtabs[Sp] = d;
+        // saturation points of the table: delta == P-1 for every q-k >= rsat_pos, delta == 0 for every q-k <= rsat_neg
+        int rp = Sp, rn = -Sp;
+        for (int r = Sp - 1; r >= -(Sp - 1) && t[r + Sp - 1] == 2 * (c.pos_buckets > 0 ? c.pos_buckets : c.max_rel_pos) - 1; --r) rp = r;
+        for (int r = -(Sp - 1); r <= Sp - 1 && t[r + Sp - 1] == 0; ++r) rn = r;
+        e->dsat[Sp] = std::make_pair(rp, rn);
     }
     return true;
 }
@@ -230,6 +236,8 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         if (last) break;
         { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+        static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
+        if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;

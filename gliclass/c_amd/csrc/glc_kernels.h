@@ -58,6 +58,9 @@ struct AttnArgs {
     int B, nh, Sp, H, P;
     // optional row selection (simple kernel only): query r is row sel_q[r] of sequence sel_b[r]; its projected
     // query is row r of the row-major Qrow [nsel, H]; output row r of CTX
+    // band kernel: q-k >= rsat_pos => delta == P-1 ; q-k <= rsat_neg => delta == 0 (table saturation, host-computed;
+    // Sp / -Sp when the table does not saturate)
+    int rsat_pos = 1 << 30, rsat_neg = -(1 << 30);
     const int* sel_b = nullptr; const int* sel_q = nullptr; const void* Qrow = nullptr; int nsel = 0;
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)

@@ -44,7 +44,8 @@ MODEL_SYMBOLS = ["flatten_int_array", "create_tensor", "prepare_input_tensors", 
                  "initialize_ort_environment", "create_ort_session", "run_inference", "parallel_inference",
                  "glc_session_num_devices", "parallel_preprocess", "parallel_postprocess", "sigmoid",
                  "process_output_tensor", "OrtGetApiBase", "g_ort", "glc_weights_load", "glc_weights_free",
-                 "glc_prng_fill", "glc_fnv1a64", "glc_named_config", "glc_tensor_spec"]
+                 "glc_prng_fill", "glc_fnv1a64", "glc_named_config", "glc_tensor_spec", "prepare_input", "prepare_inputs",
+                 "free_prepared_inputs"]
 
 _hip = None
 _model = None
@@ -109,6 +110,11 @@ def model():
         L.glc_session_num_devices.argtypes = [C.c_void_p]
         L.sigmoid.restype = C.c_float
         L.sigmoid.argtypes = [C.c_float]
+        L.prepare_input.restype = C.c_void_p
+        L.prepare_input.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_bool]
+        L.prepare_inputs.restype = C.POINTER(C.c_void_p)
+        L.prepare_inputs.argtypes = [C.POINTER(C.c_char_p), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_bool, C.c_bool]
+        L.free_prepared_inputs.argtypes = [C.c_void_p, C.c_size_t]
         L.glc_weights_load.argtypes = [C.c_char_p, C.POINTER(Weights)]
         L.glc_weights_free.argtypes = [C.POINTER(Weights)]
         L.glc_prng_fill.argtypes = [C.c_uint64, C.c_char_p, C.c_size_t, C.c_double, C.c_double, C.c_void_p]

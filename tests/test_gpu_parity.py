@@ -197,6 +197,43 @@ def test_model_h_drop_in_path(weights_for):
     del os.environ["GLICLASS_DTYPE"]
 
 
+def test_checkpoint_import_path_vs_live_hf(tmp_path):
+    """an HF DebertaV2Model state_dict (+ head tensors) -> weights.from_state_dict -> .glcw blob ->
+    create_ort_session(path) -> run_inference, compared with the live HF forward of the SAME module."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    import hf_ref
+    from gliclass.c_amd import _lib, synth, weights
+    from gliclass.c_amd.config import CONFIGS
+    cfg = CONFIGS["mini"]
+    base = weights.make_weights(cfg, 5)
+    torch.manual_seed(0)
+    model = hf_ref.build_hf_model(cfg, base)
+    with torch.no_grad():                                  # perturb so the blob really comes from the module
+        for p in model.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    sd = {"encoder_model.model." + k: v for k, v in model.state_dict().items()}   # gliclass-style prefix
+    sd.update({k: torch.from_numpy(v) for k, v in base.items() if "projector" in k})
+    tensors = weights.from_state_dict(sd, cfg)
+    path = str(tmp_path / "mini.glcw")
+    weights.write_blob(path, cfg, tensors)
+    ids, mask, _ = synth.make_inputs(cfg, 3, 90, 3, seed=9, ragged=True)
+    ref = hf_ref.forward(cfg, tensors, ids, mask, model=model)
+    m = _lib.model()
+    os.environ["GLICLASS_DTYPE"] = "f32"
+    m.initialize_ort_api()
+    sess = m.create_ort_session(m.initialize_ort_environment(), path.encode(), 8)
+    del os.environ["GLICLASS_DTYPE"]
+    assert sess
+    i64, m64 = np.ascontiguousarray(ids, np.int64), np.ascontiguousarray(mask, np.int64)
+    a = m.create_tensor(i64.ctypes.data, 3, 90)
+    b = m.create_tensor(m64.ctypes.data, 3, 90)
+    out = m.run_inference(sess, a, b)
+    assert out and list(out.contents.dims[:2]) == [3, 3]
+    got = np.ctypeslib.as_array(C.cast(out.contents.data, C.POINTER(C.c_float)), shape=(3, 3)).copy()
+    assert np.abs(sig(got) - sig(ref)).max() <= 1e-4
+
+
 def test_full_size_base_row_vs_oracle(weights_for):
     """BASELINE config c3's model (gliclass-base shape) at S=1024: one row against the fp32 CPU oracle,
     plus batch-position invariance at B=8."""

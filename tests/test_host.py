@@ -37,8 +37,10 @@ def test_every_declared_symbol_is_exported(libs):
             assert hasattr(model, name), (hdr, name)
     assert hasattr(model, "OrtGetApiBase") and hasattr(model, "g_ort")
     # externally supplied pieces (reference's src/preprocessor.c / src/tokenizer.c) are weak, not exported
-    for name in _declared_functions("tokenizer.h") | _declared_functions("preprocessor.h"):
-        assert name in ("tokenize_inputs", "free_tokenized_inputs", "prepare_inputs", "prepare_input", "free_prepared_inputs")
+    for name in _declared_functions("preprocessor.h"):
+        assert hasattr(model, name), name
+    # the tokenizer (Rust tokenizers-cpp behind the reference's src/tokenizer.c) is supplied by the integrator
+    assert _declared_functions("tokenizer.h") == {"tokenize_inputs", "free_tokenized_inputs"}
 
 
 def test_no_gpu_means_loud_failure(libs):
@@ -114,6 +116,32 @@ def test_weight_sources_synthetic_and_blob(libs, tmp_path):
     bad = tmp_path / "bad.glcw"
     bad.write_bytes(b"\0" * 512)
     assert model.glc_weights_load(str(bad).encode(), C.byref(W)) != 0
+
+
+def test_prompt_builder_matches_reference_strings(libs):
+    """/root/reference/src/preprocessor.c:67-111: "<<LABEL>>" + lower(label) ..., "<<SEP>>", prompt_first order."""
+    _lib, hip, model = libs
+
+    def one(text, labels, prompt_first):
+        arr = (C.c_char_p * max(len(labels), 1))(*[l.encode() for l in labels])
+        p = model.prepare_input(text.encode(), arr, len(labels), prompt_first)
+        out = C.string_at(p).decode()
+        C.CDLL(None).free(C.c_void_p(p))
+        return out
+    assert one("Some Text.", ["Format", "MODEL x"], True) == "<<LABEL>>format<<LABEL>>model x<<SEP>>Some Text."
+    assert one("Some Text.", ["Format", "MODEL x"], False) == "Some Text.<<LABEL>>format<<LABEL>>model x<<SEP>>"
+    assert one("t", [], True) == "<<SEP>>t" and one("", ["A"], False) == "<<LABEL>>a<<SEP>>"
+    texts = (C.c_char_p * 2)(b"one", b"two")
+    l0 = (C.c_char_p * 2)(b"X", b"y")
+    l1 = (C.c_char_p * 1)(b"Zed")
+    labs = (C.POINTER(C.c_char_p) * 2)(C.cast(l0, C.POINTER(C.c_char_p)), C.cast(l1, C.POINTER(C.c_char_p)))
+    nl = (C.c_size_t * 2)(2, 1)
+    out = model.prepare_inputs(texts, labs, 2, nl, False, True)
+    assert [C.string_at(out[i]).decode() for i in range(2)] == ["<<LABEL>>x<<LABEL>>y<<SEP>>one", "<<LABEL>>zed<<SEP>>two"]
+    model.free_prepared_inputs(out, 2)
+    out = model.prepare_inputs(texts, labs, 2, nl, True, False)        # same_labels: slot 0 for every text
+    assert [C.string_at(out[i]).decode() for i in range(2)] == ["one<<LABEL>>x<<LABEL>>y<<SEP>>", "two<<LABEL>>x<<LABEL>>y<<SEP>>"]
+    model.free_prepared_inputs(out, 2)
 
 
 def _ragged_rows(rows):

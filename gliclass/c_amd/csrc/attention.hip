@@ -26,6 +26,7 @@
 // and the next tile's K / PK / PQ fragments are prefetched under the current tile's MFMAs.
 // Key rows are loaded in the order pi(r) = swap(bit2,bit3) so that the accumulator-as-operand k
 // permutation of the P*V MFMA lines up with 8 CONTIGUOUS keys of V^T (one 16-B load per lane).
+#include <stdlib.h>
 #include "glc_common.h"
 #include "glc_kernels.h"
 #include "glc_layout.h"
@@ -40,7 +41,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T>
+template <typename T, bool UNROLL6>
 __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     typedef typename Frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LROW];
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     sat_tiles(0, kt_a, a.P - 1);
 
     if (kt_a < kt_b) {
+    // Fragment sets are addressed STATICALLY (runtime-indexed register arrays would go to scratch): the K set
+    // alternates with period 2 and the PQ sets rotate with period 3 (low block -> high block -> dead), so the
+    // loop is unrolled 6x and no register copies are needed to slide the band.
+    frag_t KF[2][4], PQ[3][4];
     // ---- band prologue: c2p blocks L(kt_a-1), L(kt_a) -> their ring halves; PQ fragments of both; K of tile kt_a ----
-    frag_t kf[4], pq_lo[4], pq_hi[4];
     {
         frag_t pk[4];
         f32x16 bacc;
         int d = block_delta(kt_a - 1);
         load_pk(d, pk);
-        load_pq(d, pq_hi);
+        load_pq(d, PQ[2]);                   // step 0: low = PQ[0], high = PQ[2]
 #pragma unroll
         for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
@@ -219,23 +223,22 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         band_store(c2p_l + c * LROW + (((kt_a - 1) & 1) << 5), bacc);
         d = block_delta(kt_a);
         load_pk(d, pk);
-        load_pq(d, pq_lo);
+        load_pq(d, PQ[0]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
         band_store(c2p_l + c * LROW + ((kt_a & 1) << 5), bacc);
-        load_tile(Kp, kt_a, kf);
+        load_tile(Kp, kt_a, KF[0]);
     }
     int d_next = block_delta(kt_a + 1 < kt_b ? kt_a + 1 : kt_a);
 
-    for (int kt = kt_a; kt < kt_b; ++kt) {
+    auto band_tile = [&](int kt, frag_t (&kf)[4], frag_t (&n_kf)[4], frag_t (&pq_lo)[4], frag_t (&pq_hi)[4], frag_t (&n_pq)[4]) {
         // ---- prefetch the next tile's operands (clamped re-load on the last tile) ----
         const int ktn = kt + 1 < kt_b ? kt + 1 : kt;
-        frag_t n_kf[4], n_pq[4], pk[4];
         load_tile(Kp, ktn, n_kf);
         load_pq(d_next, n_pq);
-        load_pk(d_next, pk);
+        const int d_pk = d_next;
         d_next = block_delta(kt + 2 < kt_b ? kt + 2 : ktn);
 
         // ---- S^T = K Q^T ; reg i <-> key k0 + 16*(i>>3) + 8h + (i&7) ----
@@ -270,6 +273,8 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             const int rr = rr_base - kc;
             sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(prow + 4 * h) * LROW + rr];
         }
+        frag_t pk[4];
+        load_pk(d_pk, pk);                      // needed only after the softmax: its latency hides under it
         softmax_pv(sv, kt);
 
         // ---- c2p band of the NEXT tile's low block L(kt+1) -> ring half (kt+1)&1 (held L(kt-1), now dead) ----
@@ -282,10 +287,22 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             wave_lds_sync();              // this tile's gathers retire before the ring slot is overwritten
             band_store(c2p_l + c * LROW + (xr ^ 32), bacc);
         }
-        // ---- slide: the low block becomes the high block of the next key tile ----
+    };
+#define GLC_BAND_STEP(J)                                                                               \
+    band_tile(kt, KF[(J) & 1], KF[((J) + 1) & 1], PQ[(J) % 3], PQ[((J) + 2) % 3], PQ[((J) + 1) % 3]); \
+    if (++kt >= kt_b) break;
+    if constexpr (UNROLL6) {
+        for (int kt = kt_a;;) {
+            GLC_BAND_STEP(0) GLC_BAND_STEP(1) GLC_BAND_STEP(2) GLC_BAND_STEP(3) GLC_BAND_STEP(4) GLC_BAND_STEP(5)
+        }
+    } else {                                   // rolled form: slide by copying the fragment sets
+        for (int kt = kt_a; kt < kt_b; ++kt) {
+            band_tile(kt, KF[0], KF[1], PQ[0], PQ[2], PQ[1]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { pq_hi[s] = pq_lo[s]; pq_lo[s] = n_pq[s]; kf[s] = n_kf[s]; }
+            for (int s = 0; s < 4; ++s) { PQ[2][s] = PQ[0][s]; PQ[0][s] = PQ[1][s]; KF[0][s] = KF[1][s]; }
+        }
     }
+#undef GLC_BAND_STEP
     }
 
     sat_tiles(kt_b, nkt, 0);
@@ -386,8 +403,14 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     if (impl == 2) {
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
-        if (dtype == GLC_DT_BF16) hipLaunchKernelGGL(attn_band_kernel<bf16_t>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(attn_band_kernel<f16_t>, grid, block, 0, st, a);
+        static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: 6x-unrolled band loop (A/B switch)
+        if (dtype == GLC_DT_BF16) {
+            if (unroll6) hipLaunchKernelGGL((attn_band_kernel<bf16_t, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_band_kernel<bf16_t, false>), grid, block, 0, st, a);
+        } else {
+            if (unroll6) hipLaunchKernelGGL((attn_band_kernel<f16_t, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((attn_band_kernel<f16_t, false>), grid, block, 0, st, a);
+        }
         return nullptr;
     }
     const size_t shm = (size_t)(64 + 256 + a.Sp) * sizeof(float);

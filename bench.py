@@ -196,8 +196,16 @@ def main():
             dom = max((n for n in per if n in fl), key=lambda n: per[n]["avg_ms"] * per[n]["launches_per_fwd"])
             peak = PEAK_TFLOPS[args.dtype]
             e2e = cfg.flops_per_seq(S, Cn) * seqs_per_s / world / 1e12
+            traffic, traffic_src = None, None
+            try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be live)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if dom in tj.get("kernels", {}) and args.dtype == "f16" and (args.config, B, S) == ("base", 64, 1024):
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/traffic.json (" + tj.get("source", "?") + ")"
+            except Exception:
+                pass
             roof = dict(bound="mfma", kernel=dom, achieved=per[dom]["tflops"], peak=peak, unit="TFLOP/s",
-                        frac=round(per[dom]["tflops"] / peak, 4), traffic=None,
+                        frac=round(per[dom]["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_src,
                         flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
                         e2e_achieved=round(e2e, 1), e2e_frac=round(e2e / peak, 4), per_kernel=per)
         cpu = None

@@ -9,8 +9,11 @@
 //     bank conflicts are removed by an XOR swizzle of the 16-B chunk index, chunk ^= (row>>1)&7,
 //     applied to the per-lane SOURCE address (the DMA destination is lane-linear) and to the
 //     ds_read_b128 address — the same involution on both sides;
-//   * two 64 KiB stages: the DMA of K-tile t+1 is in flight while the MFMAs of tile t run; one
-//     s_waitcnt vmcnt(0) + s_barrier per K-tile;
+//   * two 64 KiB stages: the DMA of K-tile t+1 is in flight while the MFMAs of tile t run; its 8 issue
+//     slots per wave are spread between the MFMA groups (a burst at the loop top starves the matrix pipe:
+//     +1..7 % measured); one s_waitcnt vmcnt(0) + s_barrier per K-tile.  Tried and rejected on MI355X
+//     (same-box A/B): a 4-stage BK=32 ring with counted vmcnt (-10 %, barrier per 32-deep step), a 128x256
+//     tile with two resident workgroups (-10..-25 %, 1.5x DMA bytes per FLOP), a software L2 prefetch (-8 %);
 //   * workgroup ids are remapped so that the tiles of one XCD (blockIdx % 8) are consecutive in
 //     (m, n) order: the n-tiles of an A panel share one L2.
 #include <stdlib.h>
@@ -289,7 +292,7 @@ bool glc_gemm256_supported(int dtype, const GemmArgs& a) {
 // K % 64 == 0; EPI_QKV: H % 256 == 0 (a tile never straddles Q|K|V), Sp % 64 == 0.
 const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a_in) {
     GemmArgs a = a_in;
-    static const int env_spread = getenv("GLC_GEMM_SPREAD") ? atoi(getenv("GLC_GEMM_SPREAD")) : 0;   // developer A/B switch
+    static const int env_spread = getenv("GLC_GEMM_SPREAD") ? atoi(getenv("GLC_GEMM_SPREAD")) : 1;   // default on (A/B switch)
     a.spread_dma = env_spread;
     if (!glc_gemm256_supported(dtype, a)) return "gemm256: unsupported shape";
     if (!a.A || !a.W) return "gemm256: null operand";

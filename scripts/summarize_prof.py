@@ -32,6 +32,7 @@ if st:
         name = r.get("Name") or r.get("KernelName") or ""
         print(f'{short(name):92s} calls={r.get("Calls")} avg_us={float(r.get("AverageNs", 0))/1e3:9.1f} total_ms={float(r.get("TotalDurationNs", 0))/1e6:9.2f} pct={r.get("Percentage")}')
 
+traffic = {}
 for tag, corr in (("fetch", 2.0), ("write", 1.0)):
     f = find(f"pmc_{tag}/**/*counter_collection.csv")
     if not f:
@@ -50,3 +51,16 @@ for tag, corr in (("fetch", 2.0), ("write", 1.0)):
     print("columns:", cols)
     for name, (tot, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]:
         print(f"{name:92s} launches={n:5d} avg_MB={tot / n * 1024 * corr / 1e6:10.2f}")
+    for name, (tot, n) in acc.items():
+        traffic.setdefault(name, {})[tag + "_bytes_per_launch"] = tot / n * 1024 * corr
+
+# bench.py reads this (committed as profiles/traffic.json) for roofline.traffic of its dominant kernel class
+import json
+cls = {"attention": "attn_band_kernel", "gemm_ffn1_gelu": "gemm256_kernelIDF16_Li1ELb0", "gemm_qkv": "gemm256_kernelIDF16_Li3ELb0"}
+outj = {}
+for c, pat in cls.items():
+    for name, v in traffic.items():
+        if pat in name and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
+            outj[c] = dict(kernel=name, hbm_bytes_per_launch=v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], **v)
+json.dump(dict(source=os.path.basename(out.rstrip("/")), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH x2 (gfx950)", kernels=outj),
+          open(os.path.join(out, "traffic.json"), "w"), indent=1)

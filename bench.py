@@ -108,7 +108,7 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GLC_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist_
         dist = dist_
         torch.cuda.set_device(local_rank)

@@ -24,6 +24,9 @@
 // the lower block of tile kt.  Per key tile only one new block of PK/PQ rows is loaded, the c2p band
 // (a function of (rel, q) only) is computed for that block alone and kept in a 2-slot LDS ring,
 // and the next tile's K / PK / PQ fragments are prefetched under the current tile's MFMAs.
+// Tried and rejected (same-box A/B, see git history "attn_band2"): one wave owning two query tiles at one
+// wave per SIMD (shared K/V/PQ loads, 36 instead of 40 MFMA per tile pair) — bit-identical results but 33 %
+// slower: hipcc's schedule does not overlap the two tiles well enough to replace two-wave TLP.
 // Key rows are loaded in the order pi(r) = swap(bit2,bit3) so that the accumulator-as-operand k
 // permutation of the P*V MFMA lines up with 8 CONTIGUOUS keys of V^T (one 16-B load per lane).
 #include <stdlib.h>
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     const int q0 = ((jj % nqb) * 4 + wave) * 32;
     if (bh >= a.B * a.nh || q0 >= Sp) return;  // whole wave leaves; no workgroup barriers below
     const int b = bh / a.nh, hh = bh - b * a.nh;
+    if (a.tile_flag && !a.tile_flag[(size_t)b * (Sp >> 5) + (q0 >> 5)]) return;   // pruned last layer: no selected row in this query tile
 
     // fragment-major operands (glc_layout.h): one tile = 4 (or 2x2) units of 64 lanes x 16 B
     const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64 + lane * 8;
@@ -317,317 +321,6 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// attn_band2_kernel: same algebra as attn_band_kernel, but one wave owns TWO adjacent 32-query tiles (A = q0..,
-// B = q0+32..) and runs alone on its SIMD (4 waves / block, 1 block / CU, up to 512 VGPRs):
-//   * K, V^T, PQ and PK fragments are loaded once per key tile for both query tiles (16 instead of 2x20 loads);
-//   * the p2c band depends on (q-k, key) only: B's window is A's shifted by one 32-block, so three block products
-//     [rr 0..95][key] serve both tiles (12 instead of 16 MFMA); B gathers at rr + 32;
-//   * c2p of block t for tile B is produced one key tile after tile A's (same PK fragments, kept one tile longer);
-//   * the two tiles are independent instruction streams inside one wave: the scheduler overlaps one tile's
-//     softmax VALU / LDS gathers with the other's MFMAs (the 2-waves-per-SIMD form is issue-bound: MFMA 33 % +
-//     VALU 46 % + LDS 22 % of the cycles, barely overlapping).
-// Fragment sets are named statically: K period 2, PK period 2, PQ period 4 (window of blocks t, t-1, t-2 + the
-// prefetched t+1) -> the band loop is unrolled 4x.  Step index j = kt - kt_a.
-template <typename T>
-__global__ __launch_bounds__(256, 1) void attn_band2_kernel(AttnArgs a) {
-    typedef typename Frag<T>::type frag_t;
-    extern __shared__ __attribute__((aligned(16))) float lds2[];
-    constexpr int P2ROW = 100;                       // floats per p2c row: 96 rr + 4 pad
-    constexpr int WAVE_LDS = 2 * 32 * LROW + 32 * P2ROW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int Sp = a.Sp;
-    const int nqb = (Sp + 255) >> 8;
-    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int bh = xcd + 8 * (jj / nqb);
-    const int q0 = ((jj % nqb) * 4 + wave) * 64;
-    if (bh >= a.B * a.nh || q0 >= Sp) return;        // whole wave leaves; no workgroup barriers below
-    const int b = bh / a.nh, hh = bh - b * a.nh;
-
-    const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64 + lane * 8;
-    const T* __restrict__ Kp = reinterpret_cast<const T*>(a.Kh) + (size_t)bh * Sp * 64 + lane * 8;
-    const T* __restrict__ Vp = reinterpret_cast<const T*>(a.Vt) + (size_t)bh * 64 * Sp + lane * 8;
-    const T* __restrict__ PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64 + 32 * 8 * h;
-    const T* __restrict__ PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64 + 32 * 8 * h;
-    const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
-    const int32_t* __restrict__ dtab = a.dtab;
-    float* c2p_l[2] = {lds2 + (size_t)wave * WAVE_LDS, lds2 + (size_t)wave * WAVE_LDS + 32 * LROW};
-    float* p2c_l = lds2 + (size_t)wave * WAVE_LDS + 2 * 32 * LROW;
-
-    int nkt = (a.klen[b] + 31) >> 5;
-    nkt = nkt < 1 ? 1 : (nkt > (Sp >> 5) ? (Sp >> 5) : nkt);
-    const int kfirst = a.kfirst[b];
-    const int foff = 8 * h;
-
-    // delta of row c of relative-distance block t (tile A's numbering): rel = q0 - 32 t - 31 + c
-    auto block_delta = [&](int t) -> int {
-        int idx = q0 - 32 * t - 31 + c + Sp - 1;
-        idx = idx < 0 ? 0 : (idx > 2 * Sp - 2 ? 2 * Sp - 2 : idx);
-        return dtab[idx];
-    };
-    auto load_tile = [&](const T* base, int tile, frag_t (&f)[4]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + (size_t)tile * 2048 + s * 512);
-    };
-    auto load_pq = [&](int d, frag_t (&f)[4]) {
-        const T* p = PQp + (size_t)(d >> 5) * 2048 + (d & 31) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 512);
-    };
-    auto load_pk = [&](int d, frag_t (&f)[4]) {
-        const T* p = PKp + (size_t)(d >> 5) * 2048 + glc_pi32(d & 31) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 512);
-    };
-    auto band_store = [&](float* dst, const f32x16& v) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = (f32x4){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-    };
-    auto zero16 = [](f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = 0.f;
-    };
-
-    frag_t qf[2][4];
-    load_tile(Qp, 0, qf[0]);
-    load_tile(Qp, 1, qf[1]);
-
-    f32x16 o0[2], o1[2];
-    float m[2] = {-3.0e38f, -3.0e38f}, l[2] = {0.f, 0.f};
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) { zero16(o0[qi]); zero16(o1[qi]); }
-    const int rr_base = c - 8 * h + 31;
-
-    // key bias + online softmax (log2 units, deferred rescale) for both query tiles, then P*V with shared V^T
-    auto softmax_pv = [&](float (&sv)[2][16], int kt) {
-        const int k0 = kt * 32;
-        frag_t vt[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            vt[0][t] = *reinterpret_cast<const frag_t*>(Vp + (size_t)kt * 2048 + t * 512);
-            vt[1][t] = *reinterpret_cast<const frag_t*>(Vp + (size_t)kt * 2048 + 1024 + t * 512);
-        }
-        if (k0 + 32 > kfirst) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff);
-            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff + 4);
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { sv[qi][i] += b0[i]; sv[qi][4 + i] += b1[i]; sv[qi][8 + i] += b2[i]; sv[qi][12 + i] += b3[i]; }
-        }
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            float mx = sv[qi][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[qi][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (__builtin_amdgcn_ballot_w64(mx - m[qi] > RESCALE_THR) != 0ull) {
-                const float mnew = fmaxf(m[qi], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m[qi] - mnew);
-                m[qi] = mnew;
-                l[qi] *= alpha;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { o0[qi][i] *= alpha; o1[qi][i] *= alpha; }
-            }
-        }
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            float psum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sv[qi][i] = __builtin_amdgcn_exp2f(sv[qi][i] - m[qi]); psum += sv[qi][i]; }
-            l[qi] += psum;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                frag_t pfr;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[qi][8 * t + j];
-                mma32(vt[0][t], pfr, o0[qi]);
-                mma32(vt[1][t], pfr, o1[qi]);
-            }
-    };
-
-    // saturated key tiles for BOTH query tiles (constant delta d*)
-    auto sat_tiles = [&](int kt_lo, int kt_hi, int dstar) {
-        if (kt_lo >= kt_hi) return;
-        frag_t pqb[4], pkb[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            pqb[s] = *reinterpret_cast<const frag_t*>(PQp + (size_t)(dstar >> 5) * 2048 + (dstar & 31) * 8 + s * 512);
-            pkb[s] = *reinterpret_cast<const frag_t*>(PKp + (size_t)(dstar >> 5) * 2048 + glc_pi32(dstar & 31) * 8 + s * 512);
-        }
-        float cq[2];
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            f32x16 t;
-            zero16(t);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pkb[s], qf[qi][s], t);
-            cq[qi] = t[0];
-        }
-        frag_t kf[4];
-        load_tile(Kp, kt_lo, kf);
-        for (int kt = kt_lo; kt < kt_hi; ++kt) {
-            frag_t n_kf[4];
-            load_tile(Kp, kt + 1 < kt_hi ? kt + 1 : kt, n_kf);
-            f32x16 kp;                                                  // K_k . PQ[d*]: the same for both query tiles
-            zero16(kp);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(kf[s], pqb[s], kp);
-            float sv[2][16];
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                f32x16 sacc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[i] = cq[qi];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(kf[s], qf[qi][s], sacc);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sv[qi][i] = sacc[i] + kp[i];
-            }
-            softmax_pv(sv, kt);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) kf[s] = n_kf[s];
-        }
-    };
-
-    int kt_a = q0 - 31 - a.rsat_pos >= 0 ? (q0 - 31 - a.rsat_pos) / 32 + 1 : 0;       // tile A saturated high => tile B too
-    kt_a = kt_a > nkt ? nkt : kt_a;
-    int kt_b = (q0 + 32 + 31 - a.rsat_neg + 31) / 32;                                  // tile B saturated low => tile A too
-    kt_b = kt_b < kt_a ? kt_a : (kt_b > nkt ? nkt : kt_b);
-
-    sat_tiles(0, kt_a, a.P - 1);
-
-    if (kt_a < kt_b) {
-        frag_t KF[2][4], PK[2][4], PQ[4][4];
-        // ---- prologue (step j = 0 <-> tile kt_a): PQ blocks t = kt_a, kt_a-1, kt_a-2 -> PQ[0], PQ[3], PQ[2];
-        //      c2p A: blocks kt_a (half 0), kt_a-1 (half 1); c2p B: blocks kt_a-1 (half 0), kt_a-2 (half 1);
-        //      PK[0] = block kt_a (tile B's next low block is computed from it in step 0)
-        {
-            f32x16 bacc;
-            frag_t pk[4];
-            int d = block_delta(kt_a - 2);
-            load_pq(d, PQ[2]);
-            load_pk(d, pk);
-            zero16(bacc);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[1][s], bacc);
-            band_store(c2p_l[1] + c * LROW + 32, bacc);
-            d = block_delta(kt_a - 1);
-            load_pq(d, PQ[3]);
-            load_pk(d, pk);
-            zero16(bacc);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[1][s], bacc);
-            band_store(c2p_l[1] + c * LROW, bacc);
-            zero16(bacc);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[0][s], bacc);
-            band_store(c2p_l[0] + c * LROW + 32, bacc);
-            d = block_delta(kt_a);
-            load_pq(d, PQ[0]);
-            load_pk(d, PK[0]);
-            zero16(bacc);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(PK[0][s], qf[0][s], bacc);
-            band_store(c2p_l[0] + c * LROW, bacc);
-            load_tile(Kp, kt_a, KF[0]);
-        }
-        int d_next = block_delta(kt_a + 1 < kt_b ? kt_a + 1 : kt_a);
-
-        // one key tile for both query tiles.  j = kt - kt_a selects the static fragment sets.
-        auto band_tile = [&](int kt, int jpar, frag_t (&kf)[4], frag_t (&n_kf)[4], frag_t (&pq0)[4], frag_t (&pq1)[4], frag_t (&pq2)[4],
-                             frag_t (&n_pq)[4], frag_t (&pk_prev)[4], frag_t (&pk_new)[4]) {
-            const int ktn = kt + 1 < kt_b ? kt + 1 : kt;
-            load_tile(Kp, ktn, n_kf);
-            load_pq(d_next, n_pq);
-            const int d_pk = d_next;
-            d_next = block_delta(kt + 2 < kt_b ? kt + 2 : ktn);
-
-            f32x16 sacc[2];
-#pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                zero16(sacc[qi]);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(kf[s], qf[qi][s], sacc[qi]);
-            }
-            // p2c band over three blocks: columns [0,32) block t = kt, [32,64) t = kt-1, [64,96) t = kt-2
-            {
-                f32x16 bacc;
-                zero16(bacc);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(pq0[s], kf[s], bacc);
-                band_store(p2c_l + c * P2ROW, bacc);
-                zero16(bacc);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(pq1[s], kf[s], bacc);
-                band_store(p2c_l + c * P2ROW + 32, bacc);
-                zero16(bacc);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(pq2[s], kf[s], bacc);
-                band_store(p2c_l + c * P2ROW + 64, bacc);
-            }
-            wave_lds_sync();
-
-            const int xr = jpar << 5;
-            float sv[2][16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kc = 16 * (i >> 3) + (i & 7);
-                const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);
-                const int rr = rr_base - kc;
-                const float* prw = p2c_l + (prow + 4 * h) * P2ROW + rr;
-                sv[0][i] = sacc[0][i] + c2p_l[0][c * LROW + (rr ^ xr)] + prw[0];
-                sv[1][i] = sacc[1][i] + c2p_l[1][c * LROW + (rr ^ xr)] + prw[32];
-            }
-            load_pk(d_pk, pk_new);                   // block t = kt+1: used now for tile A, next step for tile B
-            softmax_pv(sv, kt);
-
-            // c2p of the next step's low blocks: tile A block kt+1 (fresh PK), tile B block kt (PK kept from last step)
-            {
-                f32x16 ba, bb;
-                zero16(ba);
-                zero16(bb);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(pk_new[s], qf[0][s], ba);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(pk_prev[s], qf[1][s], bb);
-                wave_lds_sync();                     // this step's gathers retire before the ring slots are overwritten
-                band_store(c2p_l[0] + c * LROW + (xr ^ 32), ba);
-                band_store(c2p_l[1] + c * LROW + (xr ^ 32), bb);
-            }
-        };
-#define GLC_BAND2_STEP(J)                                                                                                    \
-    band_tile(kt, (J) & 1, KF[(J) & 1], KF[((J) + 1) & 1], PQ[(J) & 3], PQ[((J) + 3) & 3], PQ[((J) + 2) & 3], PQ[((J) + 1) & 3], \
-              PK[(J) & 1], PK[((J) + 1) & 1]);                                                                               \
-    if (++kt >= kt_b) break;
-        for (int kt = kt_a;;) {
-            GLC_BAND2_STEP(0) GLC_BAND2_STEP(1) GLC_BAND2_STEP(2) GLC_BAND2_STEP(3)
-        }
-#undef GLC_BAND2_STEP
-    }
-
-    sat_tiles(kt_b, nkt, 0);
-
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        float lt = l[qi] + __shfl_xor(l[qi], 32, 64);
-        const float inv = 1.0f / lt;
-        T* out = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + 32 * qi + c) * a.H + hh * 64;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            store4<T>(out + 8 * g + 4 * h, o0[qi][4 * g] * inv, o0[qi][4 * g + 1] * inv, o0[qi][4 * g + 2] * inv, o0[qi][4 * g + 3] * inv);
-            store4<T>(out + 32 + 8 * g + 4 * h, o1[qi][4 * g] * inv, o1[qi][4 * g + 1] * inv, o1[qi][4 * g + 2] * inv, o1[qi][4 * g + 3] * inv);
-        }
-    }
-}
-
 // Straightforward kernel (any T, no MFMA): one block per (query row, batch*head).  Serves the fp32 mode, the
 // on-device cross-check of the band kernel, and — with a row selection — the pruned last layer, where only
 // the 1+C rows per sequence that the head reads need attention output (their positions are arbitrary, so
@@ -714,22 +407,6 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     if (impl == 2) {
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
-        static const bool band2 = getenv("GLC_ATTN_BAND2") != nullptr;          // developer A/B switch: 64 queries per wave
-        if (band2) {
-            constexpr int kLds = 4 * (2 * 32 * LROW + 32 * 100) * (int)sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_band2_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_band2_kernel<f16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
-                    return "attention: cannot raise the dynamic LDS limit";
-                attr_set = true;
-            }
-            const int nqb2 = (a.Sp + 255) / 256, bh8b = (a.B * a.nh + 7) / 8 * 8;
-            dim3 grid2(nqb2 * bh8b);
-            if (dtype == GLC_DT_BF16) hipLaunchKernelGGL(attn_band2_kernel<bf16_t>, grid2, block, kLds, st, a);
-            else hipLaunchKernelGGL(attn_band2_kernel<f16_t>, grid2, block, kLds, st, a);
-            return nullptr;
-        }
         static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: 6x-unrolled band loop (A/B switch)
         if (dtype == GLC_DT_BF16) {
             if (unroll6) hipLaunchKernelGGL((attn_band_kernel<bf16_t, true>), grid, block, 0, st, a);

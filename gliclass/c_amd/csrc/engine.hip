@@ -68,10 +68,11 @@ struct glc_engine {
     int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0, capSel = 0;
     void *Xs = nullptr, *Qs = nullptr, *CTXs = nullptr, *T1s = nullptr, *H1s = nullptr, *FFs = nullptr;   // compact rows of the pruned last layer
     int *sel_b = nullptr, *sel_q = nullptr;
+    unsigned char* tile_flag = nullptr; size_t capFlag = 0;
     void *X = nullptr, *Qh = nullptr, *Kh = nullptr, *Vt = nullptr, *CTX = nullptr, *T1 = nullptr, *H1 = nullptr, *FF = nullptr;
     float* kbias = nullptr; int *klen = nullptr, *kfirst = nullptr, *cls_pos = nullptr, *cls_cnt = nullptr;
     int64_t *d_ids = nullptr, *d_mask = nullptr;
-    float *Gt = nullptr, *Gc = nullptr, *G1t = nullptr, *G1c = nullptr, *G2t = nullptr, *G2c = nullptr, *d_logits = nullptr;
+    float *Gt = nullptr, *G1t = nullptr, *G2t = nullptr, *d_logits = nullptr;   // head rows: [text | class] groups, 128-aligned
     std::map<int, int32_t*> dtabs;
     std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
     // last forward
@@ -172,9 +173,9 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         if (!e->d_ids || !e->d_mask) return false;
         e->capIds = B * S;
     }
-    const int hr = round_up((B * (C > 0 ? C : 1)) > B ? B * (C > 0 ? C : 1) : B, 128);
+    const int hr = round_up(B, 128) + round_up(B * (C > 0 ? C : 1), 128);      // text rows then class rows, each group 128-aligned
     if (hr > e->capHeadRows) {
-        float** bufs[] = {&e->Gt, &e->Gc, &e->G1t, &e->G1c, &e->G2t, &e->G2c};
+        float** bufs[] = {&e->Gt, &e->G1t, &e->G2t};
         for (float** b : bufs) { dfree(e, *b); *b = (float*)dmalloc(e, (size_t)hr * c.hidden * sizeof(float)); if (!*b) return false; }
         e->capHeadRows = hr;
     }
@@ -187,6 +188,10 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         e->sel_b = (int*)dmalloc(e, (size_t)rsel * sizeof(int)); e->sel_q = (int*)dmalloc(e, (size_t)rsel * sizeof(int));
         if (!e->sel_b || !e->sel_q) return false;
         e->capSel = rsel;
+    }
+    {
+        const size_t nf = (size_t)B * (Sp >> 5);
+        if (nf > e->capFlag) { dfree(e, e->tile_flag); e->tile_flag = (unsigned char*)dmalloc(e, nf); if (!e->tile_flag) return false; e->capFlag = nf; }
     }
     if (!e->dtabs.count(Sp)) {
         std::vector<int32_t> t(2 * Sp - 1);
@@ -261,17 +266,26 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         Prof p(e, PC_LAST);
         const LayerW& w = e->layers[c.layers - 1];
         const int R = B * (1 + Cc), Rpad = round_up(R, 256);
+        const bool band_sel = impl == 2;     // 16-bit: band kernel on the query tiles that hold selected rows; f32: row-selection kernel
         GemmArgs g;
-        g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = 1;
+        g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = band_sel ? 0 : 1;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
         KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false);
-        KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, B, Sp, H, Cc), false);
-        GemmArgs gq;     // Q rows of the selection: the first H rows of the fused [3H,H] weight are the (pre-scaled) query projection
-        gq.A = e->Xs; gq.W = w.Wqkv; gq.bias = w.bqkv; gq.C = e->Qs; gq.Mpad = Rpad; gq.N = H; gq.K = H;
-        KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, gq), false);
-        AttnArgs a{nullptr, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTXs, B, nh, Sp, H, e->P};
-        a.sel_b = e->sel_b; a.sel_q = e->sel_q; a.Qrow = e->Qs; a.nsel = R;
-        KCHK(glc_launch_attention(st, dt, 1, a), false);
+        if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)B * (Sp >> 5), st), false);
+        KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
+        if (band_sel) {
+            AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+            a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag;
+            KCHK(glc_launch_attention(st, dt, 2, a), false);
+            KCHK(glc_launch_gather_sel(st, dt, e->CTX, e->sel_b, e->sel_q, e->CTXs, R, Sp, H), false);
+        } else {
+            GemmArgs gq;     // Q rows of the selection: the first H rows of the fused [3H,H] weight are the (pre-scaled) query projection
+            gq.A = e->Xs; gq.W = w.Wqkv; gq.bias = w.bqkv; gq.C = e->Qs; gq.Mpad = Rpad; gq.N = H; gq.K = H;
+            KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, gq), false);
+            AttnArgs a{nullptr, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTXs, B, nh, Sp, H, e->P};
+            a.sel_b = e->sel_b; a.sel_q = e->sel_q; a.Qrow = e->Qs; a.nsel = R;
+            KCHK(glc_launch_attention(st, dt, 1, a), false);
+        }
         GemmArgs o;
         o.A = e->CTXs; o.W = w.Wo; o.bias = w.bo; o.C = e->T1s; o.resid = e->Xs; o.Mpad = Rpad; o.N = H; o.K = H;
         KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false);
@@ -286,20 +300,18 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     }
     if (C > 0) {
         Prof p(e, PC_HEAD);
-        if (prune) KCHK(glc_launch_head_gather_sel(st, dt, e->Xs, e->cls_pos, ccap, e->Gt, e->Gc, B, H, C), false);
-        else KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, e->Gc, B, Sp, H, C), false);
+        float* Gc = e->Gt + (size_t)round_up(B, 128) * H;
+        if (prune) KCHK(glc_launch_head_gather_sel(st, dt, e->Xs, e->cls_pos, ccap, e->Gt, Gc, B, H, C), false);
+        else KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C), false);
+        // text rows [0, rt) and class rows [rt, rt + rc) share one fp32 buffer; one two-group GEMM per projector stage
         const int rt = round_up(B, 128), rc = round_up(B * C, 128);
         GemmArgs h;
-        h.N = H; h.K = H;
-        h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.C = e->G1t; h.Mpad = rt;
+        h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
+        h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
         KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
-        h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.C = e->G2t;
+        h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
         KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
-        h.A = e->Gc; h.W = e->headw[4]; h.bias = e->headw[5]; h.C = e->G1c; h.Mpad = rc;
-        KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
-        h.A = e->G1c; h.W = e->headw[6]; h.bias = e->headw[7]; h.C = e->G2c;
-        KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
-        KCHK(glc_launch_head_score(st, e->G2t, e->G2c, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
+        KCHK(glc_launch_head_score(st, e->G2t, e->G2t + (size_t)rt * H, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
     }
     HIPCHK(hipGetLastError(), false);
     e->lastB = B; e->lastS = S; e->lastSp = Sp;

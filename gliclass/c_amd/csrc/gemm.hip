@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const int m0 = blockIdx.y * BM, n0 = (blockIdx.x + ((EPI == EPI_QKV && p.qkv_skip_q) ? p.H / BN : 0)) * BN;
     const int K = p.K, N = p.N;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+    const bool grp2 = p.W2 != nullptr && m0 >= p.m_split;                   // block-uniform: second weight group
+    const T* __restrict__ W = reinterpret_cast<const T*>(grp2 ? p.W2 : p.W);
 
     // staging map: thread -> 16-B chunk cc of rows (tid>>3) + 32*i
     const int cc = tid & 7, srow = tid >> 3;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     }
 
     // ---------------- epilogue ----------------
-    const float* __restrict__ bias = p.bias;
+    const float* __restrict__ bias = grp2 ? p.bias2 : p.bias;
     const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;   // block-uniform (scalar) division
     if (!vmode) {
 #pragma unroll
@@ -188,6 +189,7 @@ const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& 
         if (a.H % 128 || a.N != 3 * a.H || a.Sp % 64 || a.Sp < 64 || !a.Qh || !a.Kh || !a.Vt || a.nh * 64 != a.H) return "gemm: bad QKV epilogue shape";
     } else if (!a.C) return "gemm: null output";
     if (epi == EPI_RESID && !a.resid) return "gemm: null residual";
+    if (a.W2 && (a.m_split % BM || a.m_split <= 0 || a.m_split >= a.Mpad)) return "gemm: m_split must be a tile-aligned row inside the matrix";
     switch (dtype) {
         case GLC_DT_F32: launch_t<float>(st, epi, a); break;
         case GLC_DT_BF16: launch_t<bf16_t>(st, epi, a); break;

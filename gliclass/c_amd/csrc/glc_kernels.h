@@ -19,6 +19,7 @@ struct GemmArgs {
     void* Vt = nullptr;           // V transposed, fragment-major
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
+    const void* W2 = nullptr; const float* bias2 = nullptr; int m_split = 0;   // gemm_nt (128-tile): rows >= m_split use W2 / bias2 (two-group GEMM)
     int spread_dma = 0;                     // gemm256: issue the next stage's DMA between MFMA groups instead of up front
     int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
 };
@@ -61,6 +62,7 @@ struct AttnArgs {
     // band kernel: q-k >= rsat_pos => delta == P-1 ; q-k <= rsat_neg => delta == 0 (table saturation, host-computed;
     // Sp / -Sp when the table does not saturate)
     int rsat_pos = 1 << 30, rsat_neg = -(1 << 30);
+    const unsigned char* tile_flag = nullptr;         // band kernel: [B, Sp/32] — process only query tiles whose flag is set
     const int* sel_b = nullptr; const int* sel_q = nullptr; const void* Qrow = nullptr; int nsel = 0;
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
@@ -76,7 +78,9 @@ const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* 
 // Pruned last layer: compact the rows the head reads. Row r < B: [CLS] of sequence r; row B + b*C + j: class
 // token j of sequence b (sequence start if absent). Writes Xs[r,:] = X[row,:] and the (sequence, position) lists.
 const char* glc_launch_gather_rows(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap, void* Xs,
-                                   int* sel_b, int* sel_q, int B, int Sp, int H, int C);
+                                   int* sel_b, int* sel_q, unsigned char* tile_flag, int B, int Sp, int H, int C);
+// dst[r,:] = src[(sel_b[r]*Sp + sel_q[r]),:] for r < R
+const char* glc_launch_gather_sel(hipStream_t st, int dtype, const void* src, const int* sel_b, const int* sel_q, void* dst, int R, int Sp, int H);
 // Head gather from the compact rows: Gt[b] = Xs[b]; Gc[b*C+j] = Xs[B+b*C+j] or 0 when the class token is absent.
 const char* glc_launch_head_gather_sel(hipStream_t st, int dtype, const void* Xs, const int* cls_pos, int c_cap,
                                        float* Gt, float* Gc, int B, int H, int C);

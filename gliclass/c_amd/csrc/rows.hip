@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
                                                           T* __restrict__ Xs, int* __restrict__ sel_b, int* __restrict__ sel_q,
-                                                          int B, int Sp, int H, int C) {
+                                                          unsigned char* __restrict__ tile_flag, int B, int Sp, int H, int C) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= B * (1 + C)) return;
     const int lane = threadIdx.x & 63;
@@ -155,11 +155,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
         pos = j < c_cap ? cls_pos[(size_t)b * c_cap + j] : -1;
         if (pos < 0) pos = 0;
     }
-    if (lane == 0) { sel_b[r] = b; sel_q[r] = pos; }
+    if (lane == 0) { sel_b[r] = b; sel_q[r] = pos; if (tile_flag) tile_flag[(size_t)b * (Sp >> 5) + (pos >> 5)] = 1; }
     constexpr int VEC = 16 / (int)sizeof(T);
     typedef __attribute__((ext_vector_type(VEC))) T vecT;
     const T* src = X + ((size_t)b * Sp + pos) * H;
     for (int i = lane; i < H / VEC; i += 64) reinterpret_cast<vecT*>(Xs + (size_t)r * H)[i] = reinterpret_cast<const vecT*>(src)[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_sel_kernel(const T* __restrict__ src, const int* __restrict__ sel_b, const int* __restrict__ sel_q,
+                                                         T* __restrict__ dst, int R, int Sp, int H) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef __attribute__((ext_vector_type(VEC))) T vecT;
+    const T* s = src + ((size_t)sel_b[r] * Sp + sel_q[r]) * H;
+    for (int i = lane; i < H / VEC; i += 64) reinterpret_cast<vecT*>(dst + (size_t)r * H)[i] = reinterpret_cast<const vecT*>(s)[i];
 }
 
 template <typename T>
@@ -261,12 +273,18 @@ const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, con
     return nullptr;
 }
 
+const char* glc_launch_gather_sel(hipStream_t st, int dtype, const void* src, const int* sel_b, const int* sel_q, void* dst, int R, int Sp, int H) {
+    if (R <= 0 || !src || !sel_b || !sel_q || !dst || H % 8) return "gather_sel: bad args";
+    DISPATCH_T(dtype, { hipLaunchKernelGGL(gather_sel_kernel<T>, dim3((R + 3) / 4), dim3(256), 0, st, (const T*)src, sel_b, sel_q, (T*)dst, R, Sp, H); });
+    return nullptr;
+}
+
 const char* glc_launch_gather_rows(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap, void* Xs, int* sel_b,
-                                   int* sel_q, int B, int Sp, int H, int C) {
+                                   int* sel_q, unsigned char* tile_flag, int B, int Sp, int H, int C) {
     if (B <= 0 || C < 0 || !X || !cls_pos || !Xs || !sel_b || !sel_q || H % 8) return "gather_rows: bad args";
     const int rows = B * (1 + C);
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, (T*)Xs, sel_b, sel_q, B, Sp, H, C);
+        hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, (T*)Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
     });
     return nullptr;
 }

@@ -611,7 +611,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         if (hipMemcpyAsync(bias, tmp, N * sizeof(float), hipMemcpyDeviceToDevice, e->stream)) break;
         GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K;
         const char* m = nullptr;
-        auto launch = [&]() -> const char* { return which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : which == 3 ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
+        auto launch = [&]() -> const char* { return which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
         if (m) { set_err(m); break; }
         if (hipEventRecord(e->t0, e->stream)) break;
@@ -620,6 +620,24 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         float t = 0.f;
         if (hipEventElapsedTime(&t, e->t0, e->t1)) break;
         ms = t / iters;
+        if (which == 4) {     // diagnostic: one stamped launch of the 256-tile kernel; prints per-K-tile segment cycles (s_memtime ticks)
+            unsigned long long* dbuf = nullptr;
+            if (hipMalloc((void**)&dbuf, 64 * 8 * 4 * sizeof(unsigned long long)) == hipSuccess) {
+                (void)hipMemsetAsync(dbuf, 0, 64 * 8 * 4 * sizeof(unsigned long long), e->stream);
+                GemmArgs gs = g; gs.stamps = dbuf;
+                glc_launch_gemm256(e->stream, e->dtype, epi, gs);
+                (void)hipStreamSynchronize(e->stream);
+                std::vector<unsigned long long> hs(64 * 8 * 4);
+                if (hipMemcpy(hs.data(), dbuf, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                    double s[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < 64 * 8; ++i) for (int k = 0; k < 4; ++k) s[k] += (double)hs[i * 4 + k];
+                    const double nkt = K / 64.0, n = 64 * 8;
+                    fprintf(stderr, "[stamps M=%d N=%d K=%d] per K-tile per wave (shader cycles): compute %.0f  dma_wait %.0f  barrier %.0f | whole tile %.0f cycles\n",
+                            M, N, K, s[0] / n / nkt, s[1] / n / nkt, s[2] / n / nkt, s[3] / n);
+                }
+                (void)hipFree(dbuf);
+            }
+        }
     } while (0);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(R); (void)hipFree(bias); (void)hipFree(tmp);
     return ms;

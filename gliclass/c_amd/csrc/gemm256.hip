@@ -93,11 +93,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int n_tile0
     const int asw = (arow >> 1) & 7, bsw = (brow >> 1) & 7;   // (row + 16*i) keeps (row>>1)&7
     const int nk = K / 64;
 
+    // diagnostic stamps (p.stamps != nullptr only in glc_debug_gemm_bench's stamp launch; never in the product path)
+    const bool stamp = p.stamps != nullptr;
+    unsigned long long t_cmp = 0, t_dma = 0, t_bar = 0, t_a = 0, t_b = 0, t_c = 0, t_begin = 0;
+    auto now = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    if (stamp) t_begin = now();
+
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+        if (stamp) t_a = now();
         const bool more = kt + 1 < nk;
         if (more && !spread) stage(kt + 1, buf ^ 1);
         const unsigned char* sa = smem256 + buf * STAGE + arow * ROWB;
@@ -111,8 +124,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int n_tile0
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const frag_t af = *reinterpret_cast<const frag_t*>(sa + i * 16 * ROWB + ach);
-                if (spread && more && (i & 1) == 0) {          // one DMA issue per 8 MFMAs, behind the fragment read
-                    stage_piece(kt + 1, buf ^ 1, ks * 4 + (i >> 1));
+                if (more && ((p.spread_dma == 1 && (i & 1) == 0) || (p.spread_dma == 2 && ks == 0))) {
+                    // spread_dma 1: one DMA issue per 8 MFMAs over the whole K-tile; 2: one per 4 MFMAs over its FIRST half,
+                    // so that the youngest piece still has half a K-tile of MFMAs to land behind
+                    stage_piece(kt + 1, buf ^ 1, p.spread_dma == 1 ? ks * 4 + (i >> 1) : i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!vmode) {
@@ -124,8 +139,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int n_tile0
                 }
             }
         }
+        if (stamp) { t_b = now(); t_cmp += t_b - t_a; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of tile kt+1 have landed
+        if (stamp) { t_c = now(); t_dma += t_c - t_b; }
         __builtin_amdgcn_s_barrier();                        // everyone's have; everyone is done reading `buf`
+        if (stamp) { t_bar += now() - t_c; }
+    }
+    if (stamp && blockIdx.x < 64 && lane == 0) {
+        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+        o[0] = t_cmp; o[1] = t_dma; o[2] = t_bar; o[3] = now() - t_begin;
     }
 
     // ---------------- epilogue ----------------

@@ -20,6 +20,7 @@ struct GemmArgs {
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
     const void* W2 = nullptr; const float* bias2 = nullptr; int m_split = 0;   // gemm_nt (128-tile): rows >= m_split use W2 / bias2 (two-group GEMM)
+    unsigned long long* stamps = nullptr;   // gemm256 diagnostic build only: per (block<64, wave) cycle sums [compute, dma_wait, barrier_wait, total]
     int spread_dma = 0;                     // gemm256: issue the next stage's DMA between MFMA groups instead of up front
     int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
 };

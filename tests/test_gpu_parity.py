@@ -197,6 +197,40 @@ def test_model_h_drop_in_path(weights_for):
     del os.environ["GLICLASS_DTYPE"]
 
 
+def test_pure_c_driver_end_to_end(tmp_path, weights_for):
+    """examples/run_pretokenized.c (plain C, the reference's main.c sequence): 11 ragged rows -> 2 batches of <= 8
+    (BATCH_SIZE chunking + short last chunk), printed scores must equal sigmoid(oracle logits)."""
+    import re
+    import subprocess
+    import oracle_c
+    from gliclass.c_amd import synth
+    from test_host import _build_example
+    cfg, w = weights_for("tiny")
+    exe = _build_example(tmp_path)
+    ids, mask, _ = synth.make_inputs(cfg, 11, 70, 2, seed=17, ragged=True)
+    tok = tmp_path / "tok.txt"
+    tok.write_text("\n".join(" ".join(str(int(t)) for t in ids[b, : int(mask[b].sum())]) for b in range(11)) + "\n")
+    env = dict(os.environ, GLICLASS_DTYPE="f32", GLICLASS_THRESHOLD="0.0")
+    r = subprocess.run([exe, "synthetic:tiny:42", str(tok), "multi-label", "alpha", "beta"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    got = {}
+    batch_of_line = 0
+    for line in r.stdout.splitlines():
+        m = re.match(r"  Text_(\d+) Label: (\w+), Score: ([0-9.]+)", line)
+        if m:
+            got.setdefault((int(m.group(1)), m.group(2)), []).append(float(m.group(3)))
+    # every (local text index, label) appears once per batch that has that index: indices 0-2 twice (batches of 8 and 3)
+    assert len(got[(0, "alpha")]) == 2 and len(got[(7, "alpha")]) == 1
+    scores = sorted(v for vs in got.values() for v in vs)
+    ref = []
+    for lo, hi in ((0, 8), (8, 11)):
+        S = int(mask[lo:hi].sum(1).max())                     # pad-to-longest inside each batch
+        lg = oracle_c.forward(cfg, w, ids[lo:hi, :S], mask[lo:hi, :S])
+        ref += list(sig(lg).ravel())
+    assert len(scores) == len(ref) == 22
+    assert np.abs(np.array(scores) - np.array(sorted(ref))).max() <= 2e-5      # %.6f printing + fp32 noise
+
+
 def test_checkpoint_import_path_vs_live_hf(tmp_path):
     """an HF DebertaV2Model state_dict (+ head tensors) -> weights.from_state_dict -> .glcw blob ->
     create_ort_session(path) -> run_inference, compared with the live HF forward of the SAME module."""

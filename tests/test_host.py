@@ -244,3 +244,25 @@ def test_synthetic_inputs_layout():
     lens = mask.sum(1)
     assert lens.max() == 200 and lens.min() >= 100 and (ids[mask == 0] == 0).all()
     assert all(mask[b, :lens[b]].all() for b in range(6))        # prefix masks, like the tokenizer's padding
+
+
+def _build_example(tmp_path):
+    exe = str(tmp_path / "run_pretokenized")
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "run_pretokenized.c"), "-L" + os.path.join(ROOT, "gliclass", "c_amd"),
+                           "-lgliclass_model", "-lgliclass_hip", "-Wl,-rpath," + os.path.join(ROOT, "gliclass", "c_amd"), "-fopenmp", "-o", exe])
+    return exe
+
+
+def test_pure_c_driver_builds_against_the_headers(libs, tmp_path):
+    """examples/run_pretokenized.c is the reference's main.c call sequence in plain C11 (defines g_ort itself,
+    /root/reference/main.c:33): it must compile warning-free against include/ and link against the two libraries."""
+    _lib, hip, model = libs
+    exe = _build_example(tmp_path)
+    tok = tmp_path / "tok.txt"
+    tok.write_text("1 513 7 8 514 20 21 2\n")
+    r = subprocess.run([exe, "synthetic:tiny", str(tok), "multi-label", "a"], capture_output=True, text=True)
+    if hip.glc_device_count() == 0:
+        assert r.returncode != 0 and "no MI355X/HIP device" in r.stderr         # loud failure, no CPU path
+    else:
+        assert r.returncode == 0 and "Text_0" in r.stdout

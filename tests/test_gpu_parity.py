@@ -144,6 +144,31 @@ def test_saturated_tiles_match_simple_kernel_long_sequence(engines, weights_for)
     assert np.abs(outs[0] - outs[1]).max() <= 2e-2
 
 
+def test_edge_shapes_f32_vs_oracle(engines, weights_for):
+    """Edges the reference can produce: MAX_LENGTH-class sequences (S = 4096 > 8 x max_position_embeddings), many
+    labels (C = 40), batch sizes that are not multiples of anything, and a row that is padding only."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for("tiny")
+    eng = engines("tiny", "f32")
+    ids, mask, _ = synth.make_inputs(cfg, 1, 4096, 2, seed=51)
+    assert np.abs(sig(eng.forward(ids, mask)) - sig(oracle_c.forward(cfg, w, ids, mask))).max() <= 1e-4
+    ids, mask, counts = synth.make_inputs(cfg, 3, 200, 40, seed=52, ragged=True, labels_per_row=[40, 7, 0])
+    assert list(counts) == [40, 7, 0]
+    got, ref = eng.forward(ids, mask), oracle_c.forward(cfg, w, ids, mask)
+    assert got.shape == (3, 40) and np.abs(sig(got) - sig(ref)).max() <= 1e-4
+    ids, mask, _ = synth.make_inputs(cfg, 13, 50, 2, seed=53, ragged=True)
+    ids[5] = 0
+    mask[5] = 0                                              # a batch slot that is padding only
+    got, ref = eng.forward(ids, mask), oracle_c.forward(cfg, w, ids, mask)
+    keep = np.arange(13) != 5
+    assert np.isfinite(got).all() and np.abs(sig(got[keep]) - sig(ref[keep])).max() <= 1e-4
+    # f16 band kernel on the same edges: finite, and S = 4096 within the 16-bit envelope
+    e16 = engines("tiny", "f16")
+    ids, mask, _ = synth.make_inputs(cfg, 1, 4096, 2, seed=51)
+    assert np.abs(sig(e16.forward(ids, mask)) - sig(oracle_c.forward(cfg, w, ids, mask))).max() <= TOL_PROB["f16"]
+
+
 def test_rows_are_independent_and_order_free(engines, weights_for):
     """Size-independent properties at a larger shape: permuting batch rows permutes logits; a row's
     logits do not depend on its batch mates (what makes the batch shard across GPUs)."""

@@ -611,7 +611,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         if (hipMemcpyAsync(bias, tmp, N * sizeof(float), hipMemcpyDeviceToDevice, e->stream)) break;
         GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K;
         const char* m = nullptr;
-        auto launch = [&]() -> const char* { return which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
+        auto launch = [&]() -> const char* { return which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : which == 5 ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
         if (m) { set_err(m); break; }
         if (hipEventRecord(e->t0, e->stream)) break;

@@ -1,0 +1,319 @@
+// 256x256 MFMA GEMM, STAGGERED variant of gemm256.hip (same operand contract, tile, epilogues).
+//
+// Stamps in gemm256's main loop showed, per 64-deep K-tile and wave, ~2440 cycles in the load+MFMA segment (floor 2048:
+// two waves share one SIMD's matrix pipe) plus ~800 cycles at s_waitcnt/s_barrier where the pipe idles: the two waves
+// of a SIMD execute [loads ... MFMAs ... wait] in lockstep, so nothing covers the load and wait parts.  Here:
+//   * K is consumed in 32-deep steps on a 4-slot LDS ring (32 KiB per slot), DMA issued three steps ahead, counted
+//     s_waitcnt vmcnt(8), ONE raw s_barrier per step;
+//   * the waves of a workgroup form two groups that sit pairwise on the same SIMDs (wave i and i+4).  Inside barrier
+//     interval s group 0 runs  [issue DMA(s+3), read fragments(s), MFMA(s)]  and group 1 runs
+//     [MFMA(s-1) from registers, issue DMA(s+3), read fragments(s), lgkmcnt(0)]  — on every SIMD one wave feeds the
+//     matrix pipe while its partner issues LDS reads / DMA, and they swap halfway through the interval.
+// Hazards: RAW — every wave waits vmcnt(8) (its pieces of step s landed) before barrier X_s, reads of slot s happen after
+// X_s.  WAR — the DMA issued in interval s overwrites the slot of step s-1, whose reads completed before X_s for both
+// groups (group 1 explicitly waits lgkmcnt(0) before the barrier).  The epilogue patches reuse the ring, so one more
+// barrier separates the last fragment reads from them.
+#include <stdlib.h>
+#include "glc_common.h"
+#include "glc_kernels.h"
+#include "glc_layout.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256;
+constexpr int ROWB = 64;                   // bytes of K per row per step (32 x 16-bit)
+constexpr int STAGE = (TM + TN) * ROWB;    // 32 KiB
+constexpr int NSLOT = 4;
+constexpr int EPI_PATCH = 9216;            // bytes of wave-private fp32 epilogue staging (8 x 9 KiB < 2 stages)
+extern __shared__ __attribute__((aligned(16))) unsigned char smem256s[];
+#define smem256 smem256s
+// chunk swizzle of the [rows][64 B] image: 4 rows fill the 64 banks; chunk ^= s(row>>2), s = {0,2,3,1} makes every
+// ds_read_b128 lane group of a 16-row fragment read touch 16 distinct 16-B bank slots
+__device__ __forceinline__ int swz4(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
+                                     (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+
+template <typename T, int EPI, bool VMODE>
+__global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile0, int ntn) {
+    typedef typename Frag<T>::type frag_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int K = p.K, N = p.N;
+
+    // XCD-aware tile order (bijective for any grid size)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int mt = tile / ntn, nt = tile % ntn;
+    const int m0 = mt * TM, n0 = (n_tile0 + nt) * TN;   // this launch covers n-tiles [n_tile0, n_tile0 + ntn)
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+
+    // DMA map (one wave instruction lands 16 rows x 64 B): wave w moves rows [32w + 16i, +16), i = 0,1, of the A tile and
+    // of the W tile.  Lane L lands at (row L>>2, chunk L&3) and FETCHES chunk (L&3) ^ swz4(row).
+    const int lrow = lane >> 2, lch = lane & 3;
+    const T* ga[2];
+    const T* gw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + lrow;
+        const int ch = lch ^ swz4(row);
+        ga[i] = A + (size_t)(m0 + row) * K + ch * 8;
+        gw[i] = W + (size_t)(n0 + row) * K + ch * 8;
+    }
+    auto stage = [&](int st) {
+        unsigned char* sa = smem256 + (st & (NSLOT - 1)) * STAGE + (wave * 32) * ROWB;
+        unsigned char* sw = sa + TM * ROWB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(ga[i] + (size_t)st * 32, sa + i * 16 * ROWB);
+            glds16(gw[i] + (size_t)st * 32, sw + i * 16 * ROWB);
+        }
+    };
+
+    constexpr bool vmode = VMODE;          // V third of the fused QKV projection: transposed output
+    f32x4 acc[8][4];      // [mi][ni] (lane = m) or, in vmode, the same slots with lane = n
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row r (+16 i keeps (r>>2)&3), logical chunk g -> physical g ^ swz4(r)
+    const int aoff = (wm * 128 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
+    const int boff = TM * ROWB + (wn * 64 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
+    const int nk = K / 32;
+    const bool late = wm == 1;            // group 1 runs half a step behind group 0 (one extra barrier up front)
+    frag_t af[8], bf[4];
+
+    // Every wave executes the SAME two-phase step; the stagger is purely temporal:
+    //   phase A_s : issue DMA(s+3), read the fragments of step s, lgkmcnt(0), counted vmcnt  | barrier
+    //   phase B_s : 32 MFMAs from registers                                                    | barrier
+    // Group 1 enters the loop one barrier later, so while one wave of a SIMD is in B (matrix pipe) its partner is in A
+    // (LDS reads + DMA issue).  Time slot of A_s is 2s for group 0 and 2s+1 for group 1.
+    //   RAW: step s+1 is first read at slot 2s+2; every wave makes its own pieces of step s+1 land (vmcnt) before the
+    //        barrier that ends its A_s (slot <= 2s+1).
+    //   WAR: DMA(s+3) reuses the slot of step s-1, last read at slot 2s-1 with lgkmcnt(0) before that slot's barrier.
+    stage(0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // P: step 0 is in LDS for everyone
+    if (late) __builtin_amdgcn_s_barrier();    // the stagger
+    for (int st = 0; st < nk; ++st) {
+        // ---- phase A ----
+        if (st + 3 < nk) stage(st + 3);
+        {
+            const unsigned char* sb = smem256 + (st & (NSLOT - 1)) * STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag_t*>(sb + boff + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag_t*>(sb + aoff + i * 16 * ROWB);
+        }
+        // my pieces of step st+1 have landed once only the (up to two) younger steps are outstanding
+        if (st + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (st + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!vmode) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(bf[j], af[i], acc[i][j]);   // D[n = 4g+r][m = r16]
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(af[i], bf[j], acc[i][j]);   // D[m = 4g+r][n = r16]
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();   // pairs with group 1's last barrier
+
+    // ---------------- epilogue ----------------
+    // The accumulator layout gives a lane 4 consecutive columns of one row (8-byte pieces).  Storing that
+    // directly costs 32 narrow, scattered stores per lane — as much time as a K=768 main loop.  Instead each
+    // wave stages its 128x64 sub-tile through a PRIVATE fp32 LDS patch, 32 rows at a time (the stage ring
+    // is dead after the last barrier), and writes it back as 16-byte pieces: one wave instruction = 8 rows
+    // x 128 contiguous bytes (row-major outputs) or whole 16-byte fragment units (Q / K / V^T).  Bias and
+    // GELU are applied before staging, the residual is added in fp32 at the store, so the value is rounded
+    // once, exactly as before.  Wave-local LDS ordering only; no workgroup barrier.
+    typedef __attribute__((ext_vector_type(8))) T vec8T;
+    const float* __restrict__ bias = p.bias;
+    float* stg = reinterpret_cast<float*>(smem256 + wave * EPI_PATCH);
+    const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;
+    if (!vmode) {
+        // D[n = 16j + 4g + r][m = 16i + r16]; patch [32 rows m][64 cols n], row stride 68 floats
+        const int which = (EPI == EPI_QKV) ? n0 / p.H : 0;
+        float bj[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + j * 16 + 4 * g); bj[j][0] = bv[0]; bj[j][1] = bv[1]; bj[j][2] = bv[2]; bj[j][3] = bv[3]; }
+            else { bj[j][0] = bj[j][1] = bj[j][2] = bj[j][3] = 0.f; }
+        }
+        // residual rows are fetched one 32-row chunk AHEAD of their use (16-byte coalesced loads): without this each
+        // chunk exposed a full HBM round trip between its LDS read-back and its store (+4.7 us per tile measured)
+        vec8T rpre[4];
+        auto load_resid = [&](int c, vec8T (&r)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
+                r[k] = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) +
+                                                       (size_t)(m0 + wm * 128 + c * 32 + row) * N + n0 + wn * 64 + g8 * 8);
+            }
+        };
+        if (EPI == EPI_RESID) load_resid(0, rpre);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            vec8T rcur[4];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rcur[k] = rpre[k];
+                if (c + 1 < 4) load_resid(c + 1, rpre);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[2 * c + ii][j];
+                    v[0] += bj[j][0]; v[1] += bj[j][1]; v[2] += bj[j][2]; v[3] += bj[j][3];
+                    if (EPI == EPI_GELU) {
+                        const f32x2 g0 = glc_gelu2((f32x2){v[0], v[1]}), g1 = glc_gelu2((f32x2){v[2], v[3]});
+                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                    }
+                    *reinterpret_cast<f32x4*>(stg + (ii * 16 + r16) * 68 + j * 16 + 4 * g) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int m = m0 + wm * 128 + c * 32 + row;
+                const int n = n0 + wn * 64 + g8 * 8;
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rcur[k][e];
+                }
+                vec8T o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
+                if (EPI == EPI_QKV) {
+                    if (m < p.Mvalid) {
+                        int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                        while (sq >= p.Sp) { sq -= p.Sp; ++b; }          // a 256-row tile spans <= 5 sequences (Sp >= 64)
+                        const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;     // dd is a multiple of 8: one 16-B unit
+                        const int bh = b * p.nh + hh;
+                        T* dst = which == 0 ? reinterpret_cast<T*>(p.Qh) + glc_qoff(p.Sp, bh, sq, dd)
+                                            : reinterpret_cast<T*>(p.Kh) + glc_koff(p.Sp, bh, sq, dd);
+                        *reinterpret_cast<vec8T*>(dst) = o;
+                    }
+                } else {
+                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // V third: D[m = 16i + 4g + r][n = 16j + r16]; patch [64 rows dd][32 cols key], row stride 36 floats
+        float bn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bn[j] = bias ? bias[n0 + wn * 64 + j * 16 + r16] : 0.f;
+        const int hh = (n0 + wn * 64 - 2 * p.H) >> 6;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[2 * c + ii][j];
+                    v[0] += bn[j]; v[1] += bn[j]; v[2] += bn[j]; v[3] += bn[j];
+                    *reinterpret_cast<f32x4*>(stg + (j * 16 + r16) * 36 + ii * 16 + 4 * g) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, dd = idx >> 2, kg = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8 + 4);
+                vec8T o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (T)lo[e]; o[4 + e] = (T)hi[e]; }
+                const int m = m0 + wm * 128 + c * 32 + kg * 8;           // first of 8 consecutive keys
+                if (m < p.Mvalid) {
+                    int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                    while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + glc_voff(p.Sp, b * p.nh + hh, dd, sq)) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <typename T, int EPI, bool VMODE> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256s_kernel<T, EPI, VMODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                NSLOT * STAGE) != hipSuccess)
+            return "gemm256s: cannot raise the dynamic LDS limit";
+        attr_set = true;
+    }
+    const int grid = (a.Mpad / TM) * ntn;
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
+    return nullptr;
+}
+template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmArgs& a) {
+    const int ntn = a.N / TN;
+    switch (epi) {
+        case EPI_BIAS: return launch_e<T, EPI_BIAS, false>(st, a, 0, ntn);
+        case EPI_GELU: return launch_e<T, EPI_GELU, false>(st, a, 0, ntn);
+        case EPI_RESID: return launch_e<T, EPI_RESID, false>(st, a, 0, ntn);
+        case EPI_QKV: {   // Q|K columns in row orientation, V columns transposed: two grids, one stream
+            const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;     // skip the Q columns when asked
+            const char* m = launch_e<T, EPI_QKV, false>(st, a, nq, nqk - nq);
+            return m ? m : launch_e<T, EPI_QKV, true>(st, a, nqk, ntn - nqk);
+        }
+    }
+    return "gemm256s: bad epilogue";
+}
+
+}  // namespace
+
+static bool gemm256s_supported(int dtype, const GemmArgs& a) {
+    return (dtype == GLC_DT_BF16 || dtype == GLC_DT_F16) && a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 &&
+           a.K > 0 && a.K % 32 == 0;
+}
+
+// Host-side shape contract: 16-bit T; Mpad % 256 == 0 (buffers allocated with Mpad rows), N % 256 == 0,
+// K % 64 == 0; EPI_QKV: H % 256 == 0 (a tile never straddles Q|K|V), Sp % 64 == 0.
+const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmArgs& a_in) {
+    const GemmArgs& a = a_in;
+    if (!gemm256s_supported(dtype, a)) return "gemm256s: unsupported shape";
+    if (!a.A || !a.W) return "gemm256s: null operand";
+    if (epi == EPI_QKV) {
+        if (a.H % 256 || a.N != 3 * a.H || a.Sp % 64 || a.Sp < 64 || !a.Qh || !a.Kh || !a.Vt || a.nh * 64 != a.H) return "gemm256s: bad QKV epilogue shape";
+    } else if (!a.C) return "gemm256s: null output";
+    if (epi == EPI_RESID && !a.resid) return "gemm256s: null residual";
+    return dtype == GLC_DT_BF16 ? launch_t<bf16_t>(st, epi, a) : launch_t<f16_t>(st, epi, a);
+}
+
+bool glc_gemm_use_stagger() {
+    static const bool on = getenv("GLC_GEMM_STAGGER") == nullptr || atoi(getenv("GLC_GEMM_STAGGER")) != 0;   // default on; GLC_GEMM_STAGGER=0 -> gemm256.hip
+    return on;
+}

@@ -27,10 +27,13 @@ struct GemmArgs {
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);
 const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a);    // 256x256 tile, 16-bit T
+const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmArgs& a);   // 256x256 tile, staggered wave groups (gemm256s.hip)
+bool glc_gemm_use_stagger();
 // picks the 256x256 LDS-DMA kernel when the shape allows it, else the 128x128 one
 inline const char* glc_launch_gemm_auto(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
     const bool qkv_ok = epi != EPI_QKV || a.H % 256 == 0;
-    return (glc_gemm256_supported(dtype, a) && qkv_ok) ? glc_launch_gemm256(st, dtype, epi, a) : glc_launch_gemm(st, dtype, epi, a);
+    if (!(glc_gemm256_supported(dtype, a) && qkv_ok)) return glc_launch_gemm(st, dtype, epi, a);
+    return glc_gemm_use_stagger() ? glc_launch_gemm256s(st, dtype, epi, a) : glc_launch_gemm256(st, dtype, epi, a);
 }
 
 // Row LayerNorm: Y[m,:] = LN(X[m,:]) * gamma + beta, rows [0, M).  X, Y element type T.

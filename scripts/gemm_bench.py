@@ -11,7 +11,7 @@ EPI = {"bias": 0, "gelu": 1, "resid": 2}
 shapes = [(65536, 768, k, ep) for k in (256, 768, 1536, 3072, 6144) for ep in ("bias", "resid")] + \
          [(65536, 3072, k, ep) for k in (256, 768, 1536, 3072) for ep in ("bias", "gelu")] + [(4096, 4096, 4096, "bias"), (8192, 8192, 8192, "bias")]
 for (M, N, K, ep) in shapes:
-    ms = e.L.glc_debug_gemm_bench(e.h, M, N, K, EPI[ep], 10, 4 if os.environ.get('GLC_STAMPS') else 3)
+    ms = e.L.glc_debug_gemm_bench(e.h, M, N, K, EPI[ep], 10, int(os.environ.get('GLC_WHICH', '4' if os.environ.get('GLC_STAMPS') else '3')))
     if ms < 0:
         print("ERR", e.L.glc_last_error().decode()); continue
     tiles_per_cu = (M // 256) * (N // 256) / 256.0

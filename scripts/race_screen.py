@@ -22,6 +22,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         e.close()
     print(out)
 else:
-    for env in ({}, {"GLC_GEMM_STAGGER": "1"}):
+    for env in ({}, {"GLC_GEMM_STAGGER": "0"}):
         r = subprocess.run([sys.executable, __file__, "child", "12"], env=dict(os.environ, **env), capture_output=True, text=True)
         print(env, r.stdout.strip()[-300:], r.stderr.strip()[-200:] if r.returncode else "")

@@ -44,7 +44,21 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, bool UNROLL6>
+// Diagnostic build (DIAG): s_memtime stamps at the segment boundaries of a band tile, summed per wave.
+template <bool ON> struct SegClock {
+    unsigned prev = 0, seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0;
+    bool live = false;          // only band tiles are accounted (softmax_pv is shared with the saturated tiles)
+    __device__ __forceinline__ static unsigned now() {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return (unsigned)t;
+    }
+    __device__ __forceinline__ void start() { if constexpr (ON) { prev = now(); live = true; ++tiles; } }
+    __device__ __forceinline__ void stop() { if constexpr (ON) live = false; }
+    __device__ __forceinline__ void mark(int k) { if constexpr (ON) { if (live) { const unsigned t = now(); seg[k] += t - prev; prev = t; } } }
+};
+
+template <typename T, bool UNROLL6, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     typedef typename Frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LROW];
@@ -112,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m = -3.0e38f, l = 0.f;
     const int rr_base = c - 8 * h + 31;
+    SegClock<DIAG> clk;
 
     // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V.
     auto softmax_pv = [&](float (&sv)[16], int kt) {
@@ -130,14 +145,18 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { sv[i] += b0[i]; sv[4 + i] += b1[i]; sv[8 + i] += b2[i]; sv[12 + i] += b3[i]; }
         }
-        float mx = sv[0];
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);          // v_max3 chain
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+        mx = fmaxf(mx, sv[15]);
+        clk.mark(3);
         // Deferred rescale: scores are in log2 units; the reference exponent m only moves when some row's
         // maximum outgrows it by more than RESCALE_THR (P then stays <= 2^THR, exact in fp32 sums and
-        // at unchanged relative precision in the 16-bit P operand).  Wave-uniform branch.
+        // at unchanged relative precision in the 16-bit P operand).  Wave-uniform branch.  m is identical in
+        // the two lane halves of a query (it only ever takes exchanged values), so the test needs no
+        // cross-half exchange — that LDS round trip sits in the rare branch.
         if (__builtin_amdgcn_ballot_w64(mx - m > RESCALE_THR) != 0ull) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f(m - mnew);
             m = mnew;
@@ -149,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
         l += psum;
+        clk.mark(4);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             frag_t pfr;
@@ -157,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             mma32(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
             mma32(vt[1][t], pfr, o1);     //                   dd + 32
         }
+        clk.mark(5);
     };
 
     // Saturated key tiles: every q-k of the tile lies beyond the clamp of the bucket table, so delta is ONE
@@ -240,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     auto band_tile = [&](int kt, frag_t (&kf)[4], frag_t (&n_kf)[4], frag_t (&pq_lo)[4], frag_t (&pq_hi)[4], frag_t (&n_pq)[4]) {
         // ---- prefetch the next tile's operands (clamped re-load on the last tile) ----
         const int ktn = kt + 1 < kt_b ? kt + 1 : kt;
+        clk.start();
         load_tile(Kp, ktn, n_kf);
         load_pq(d_next, n_pq);
         const int d_pk = d_next;
@@ -266,7 +288,9 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             for (int s = 0; s < 4; ++s) mma32(pq_hi[s], kf[s], bacc);
             band_store(p2c_l + c * LROW + 32, bacc);
         }
+        clk.mark(0);
         wave_lds_sync();
+        clk.mark(1);
 
         const int xr = (kt & 1) << 5;           // ring half that holds this tile's low block
         float sv[16];
@@ -277,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             const int rr = rr_base - kc;
             sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(prow + 4 * h) * LROW + rr];
         }
+        clk.mark(2);
         frag_t pk[4];
         load_pk(d_pk, pk);                      // needed only after the softmax: its latency hides under it
         softmax_pv(sv, kt);
@@ -291,6 +316,8 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
             wave_lds_sync();              // this tile's gathers retire before the ring slot is overwritten
             band_store(c2p_l + c * LROW + (xr ^ 32), bacc);
         }
+        clk.mark(6);
+        clk.stop();
     };
 #define GLC_BAND_STEP(J)                                                                               \
     band_tile(kt, KF[(J) & 1], KF[((J) + 1) & 1], PQ[(J) % 3], PQ[((J) + 2) % 3], PQ[((J) + 1) % 3]); \
@@ -311,6 +338,13 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
 
     sat_tiles(kt_b, nkt, 0);
 
+    if constexpr (DIAG) {
+        if (a.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {     // 64 blocks of XCD 0
+            unsigned long long* o = a.stamps + ((size_t)(blockIdx.x >> 3) * 4 + wave) * 8;
+            for (int k = 0; k < 7; ++k) o[k] = clk.seg[k];
+            o[7] = clk.tiles;
+        }
+    }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     T* out = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + c) * a.H + hh * 64;
@@ -407,13 +441,17 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     if (impl == 2) {
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
+        const size_t dyn = (a.variant & 2) ? 60 * 1024 : 0;     // diagnostic: pad LDS so that one block fits per CU (one wave per SIMD)
         static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: 6x-unrolled band loop (A/B switch)
-        if (dtype == GLC_DT_BF16) {
-            if (unroll6) hipLaunchKernelGGL((attn_band_kernel<bf16_t, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_band_kernel<bf16_t, false>), grid, block, 0, st, a);
+        if (a.stamps) {
+            if (dtype != GLC_DT_F16) return "attention: the stamped build exists for f16 only";
+            hipLaunchKernelGGL((attn_band_kernel<f16_t, false, true>), grid, block, dyn, st, a);   // rolled loop: room for the stamp registers
+        } else if (dtype == GLC_DT_BF16) {
+            if (unroll6) hipLaunchKernelGGL((attn_band_kernel<bf16_t, true>), grid, block, dyn, st, a);
+            else hipLaunchKernelGGL((attn_band_kernel<bf16_t, false>), grid, block, dyn, st, a);
         } else {
-            if (unroll6) hipLaunchKernelGGL((attn_band_kernel<f16_t, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((attn_band_kernel<f16_t, false>), grid, block, 0, st, a);
+            if (unroll6) hipLaunchKernelGGL((attn_band_kernel<f16_t, true>), grid, block, dyn, st, a);
+            else hipLaunchKernelGGL((attn_band_kernel<f16_t, false>), grid, block, dyn, st, a);
         }
         return nullptr;
     }

@@ -643,6 +643,64 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
     return ms;
 }
 
+/* Developer microbenchmark: re-run the band attention kernel `iters` times on the Q/K/V^T that the last forward left in the
+ * workspace (layer-0 position tables), HIP-event timed.  checksum[0..1] = sum and sum of squares of the context output;
+ * variant is passed through to the kernel; stamps != 0 adds one launch of the s_memtime-instrumented build and prints
+ * the per-tile segment cycles.  Returns ms per launch or < 0. */
+float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum) {
+    if (!e || iters <= 0 || e->dtype == GLC_F32 || e->lastB <= 0) { set_err("attn_bench: needs a 16-bit engine and a previous forward"); return -1.f; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1.f);
+    const int B = e->lastB, Sp = e->lastSp, H = e->cfg.hidden, nh = e->cfg.heads;
+    const LayerW& w = e->layers[0];
+    AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant;
+    hipStream_t st = e->stream;
+    for (int i = 0; i < 2; ++i) KCHK(glc_launch_attention(st, e->dtype, 2, a), -1.f);
+    HIPCHK(hipEventRecord(e->t0, st), -1.f);
+    for (int i = 0; i < iters; ++i) glc_launch_attention(st, e->dtype, 2, a);
+    HIPCHK(hipEventRecord(e->t1, st), -1.f);
+    HIPCHK(hipEventSynchronize(e->t1), -1.f);
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e->t0, e->t1), -1.f);
+    if (checksum) {
+        const size_t n = (size_t)B * Sp * H;
+        float* tmp = nullptr;
+        HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)), -1.f);
+        std::vector<float> h(n);
+        const char* m = glc_launch_to_f32(st, e->dtype, e->CTX, tmp, n);
+        hipError_t r = m ? hipErrorUnknown : hipMemcpyAsync(h.data(), tmp, n * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        if (r != hipSuccess) { set_err("attn_bench: readback failed"); return -1.f; }
+        double s1 = 0, s2 = 0;
+        for (size_t i = 0; i < n; ++i) { s1 += h[i]; s2 += (double)h[i] * h[i]; }
+        checksum[0] = s1; checksum[1] = s2;
+    }
+    if (stamps) {
+        unsigned long long* dbuf = nullptr;
+        const size_t ns = 64 * 4 * 8;
+        if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
+            AttnArgs as = a; as.stamps = dbuf;
+            glc_launch_attention(st, e->dtype, 2, as);
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> hs(ns);
+            if (hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double s[8] = {0};
+                for (size_t i = 0; i < 64 * 4; ++i) for (int k = 0; k < 8; ++k) s[k] += (double)hs[i * 8 + k];
+                const double nt = s[7] > 0 ? s[7] : 1;
+                fprintf(stderr, "[attn stamps] per band tile per wave (s_memtime ticks), %0.f tiles: mfma_qk_p2c+stores %.0f | lds_sync %.0f | gather %.0f | "
+                                "max+xchg %.0f | exp+sum %.0f | cvt+pv %.0f | c2p_next %.0f | total %.0f\n",
+                        nt, s[0] / nt, s[1] / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, s[6] / nt,
+                        (s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + s[6]) / nt);
+            }
+            (void)hipFree(dbuf);
+        }
+    }
+    return t / iters;
+}
+
 const glc_model_config* glc_engine_config(const glc_engine* e) { return e ? &e->cfg : nullptr; }
 int glc_engine_dtype(const glc_engine* e) { return e ? e->dtype : -1; }
 

@@ -68,9 +68,23 @@ struct AttnArgs {
     int rsat_pos = 1 << 30, rsat_neg = -(1 << 30);
     const unsigned char* tile_flag = nullptr;         // band kernel: [B, Sp/32] — process only query tiles whose flag is set
     const int* sel_b = nullptr; const int* sel_q = nullptr; const void* Qrow = nullptr; int nsel = 0;
+    // band kernel, diagnostic build only: per (block < 64, wave) cycle sums of the band-tile segments [8] (s_memtime ticks)
+    unsigned long long* stamps = nullptr;
+    int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
+
+// Kernels that need more than 64 KiB of dynamic LDS raise the per-function limit once per device.
+#include <atomic>
+template <typename F> inline bool glc_raise_lds_limit(F* kernel, int bytes, std::atomic<unsigned>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return false;
+    if (done.load(std::memory_order_acquire) >> dev & 1u) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(1u << dev, std::memory_order_release);
+    return true;
+}
 
 // Head: gather pooled rows -> Gt [B,H] and class-token rows -> Gc [B*C,H], both fp32.
 const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap,

@@ -110,6 +110,8 @@ void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out);
 
 /* Developer microbenchmark of one GEMM shape (16-bit engines): ms per launch, <0 on error. */
 float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which);
+/* Developer microbenchmark of the band attention kernel on the workspace of the last forward (see engine.hip). */
+float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum);
 
 const glc_model_config* glc_engine_config(const glc_engine* e);
 int glc_engine_dtype(const glc_engine* e);

@@ -277,13 +277,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p, int n_tile0
 }
 
 template <typename T, int EPI, bool VMODE> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<T, EPI, VMODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * STAGE) != hipSuccess)
-            return "gemm256: cannot raise the dynamic LDS limit";
-        attr_set = true;
-    }
+    static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
+    if (!glc_raise_lds_limit(gemm256_kernel<T, EPI, VMODE>, 2 * STAGE, lds_ok)) return "gemm256: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
     hipLaunchKernelGGL((gemm256_kernel<T, EPI, VMODE>), dim3(grid), dim3(512), 2 * STAGE, st, a, n_tile0, ntn);
     return nullptr;

@@ -23,7 +23,7 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int ROWB = 64;                   // bytes of K per row per step (32 x 16-bit)
 constexpr int STAGE = (TM + TN) * ROWB;    // 32 KiB
-constexpr int NSLOT = 4;
+constexpr int NSLOT = 4;                   // LDS ring slots; DMA runs 3 steps ahead (a 5-slot ring measured no faster)
 constexpr int EPI_PATCH = 9216;            // bytes of wave-private fp32 epilogue staging (8 x 9 KiB < 2 stages)
 extern __shared__ __attribute__((aligned(16))) unsigned char smem256s[];
 #define smem256 smem256s
@@ -267,13 +267,8 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 }
 
 template <typename T, int EPI, bool VMODE> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256s_kernel<T, EPI, VMODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                NSLOT * STAGE) != hipSuccess)
-            return "gemm256s: cannot raise the dynamic LDS limit";
-        attr_set = true;
-    }
+    static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
+    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
     hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
     return nullptr;

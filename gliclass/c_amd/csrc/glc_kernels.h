@@ -75,8 +75,8 @@ struct AttnArgs {
 // impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
 
-// Kernels that need more than 64 KiB of dynamic LDS raise the per-function limit once per device.
 #include <atomic>
+// Kernels that need more than 64 KiB of dynamic LDS raise the per-function limit once per device.
 template <typename F> inline bool glc_raise_lds_limit(F* kernel, int bytes, std::atomic<unsigned>& done) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return false;

@@ -1,18 +1,23 @@
-// 256x256 MFMA GEMM, STAGGERED variant of gemm256.hip (same operand contract, tile, epilogues).
+// 256x256 MFMA GEMM, STAGGERED variant of gemm256.hip (same operand contract, tile, epilogues, accumulation order —
+// outputs are bit-identical to gemm256, which scripts/race_screen.py uses as a race detector).
 //
 // Stamps in gemm256's main loop showed, per 64-deep K-tile and wave, ~2440 cycles in the load+MFMA segment (floor 2048:
 // two waves share one SIMD's matrix pipe) plus ~800 cycles at s_waitcnt/s_barrier where the pipe idles: the two waves
 // of a SIMD execute [loads ... MFMAs ... wait] in lockstep, so nothing covers the load and wait parts.  Here:
 //   * K is consumed in 32-deep steps on a 4-slot LDS ring (32 KiB per slot), DMA issued three steps ahead, counted
-//     s_waitcnt vmcnt(8), ONE raw s_barrier per step;
-//   * the waves of a workgroup form two groups that sit pairwise on the same SIMDs (wave i and i+4).  Inside barrier
-//     interval s group 0 runs  [issue DMA(s+3), read fragments(s), MFMA(s)]  and group 1 runs
-//     [MFMA(s-1) from registers, issue DMA(s+3), read fragments(s), lgkmcnt(0)]  — on every SIMD one wave feeds the
-//     matrix pipe while its partner issues LDS reads / DMA, and they swap halfway through the interval.
-// Hazards: RAW — every wave waits vmcnt(8) (its pieces of step s landed) before barrier X_s, reads of slot s happen after
-// X_s.  WAR — the DMA issued in interval s overwrites the slot of step s-1, whose reads completed before X_s for both
-// groups (group 1 explicitly waits lgkmcnt(0) before the barrier).  The epilogue patches reuse the ring, so one more
-// barrier separates the last fragment reads from them.
+//     s_waitcnt vmcnt(8|4|0), raw s_barrier;
+//   * every wave runs the SAME two-phase step — phase A: issue DMA(s+3), read the 12 fragments of step s, wait;
+//     phase B: 32 MFMAs from registers — with a barrier after each phase;
+//   * the waves of a workgroup form two groups that sit pairwise on the same SIMDs (wave i and i+4); group 1 enters the
+//     loop one barrier late (and group 0 leaves one barrier late), so on every SIMD one wave is in B (matrix pipe) while
+//     its partner is in A (LDS reads + DMA issue).  The stagger is purely temporal: no per-group code.
+// Hazards (time slot of A_s is 2s for group 0, 2s+1 for group 1): RAW — step s+1 is first read at slot 2s+2 and every
+// wave makes its own DMA pieces of step s+1 land (vmcnt) before the barrier that ends its A_s (slot <= 2s+1).  WAR —
+// DMA(s+3) reuses the slot of step s-1, last read at slot 2s-1 with lgkmcnt(0) before that slot's barrier.  The epilogue
+// patches reuse the ring: group 0's extra final barrier pairs with group 1's last loop barrier, after which no wave
+// reads the ring any more.
+// Measured (same box, f16): 4096^3 947 -> 1247 TF; 65536x768x3072 860 -> 1069 TF; 65536x3072x768+GELU 640 -> 793 TF.
+// Tried on top, no gain: DMA issue interleaved into phase B (-1..3 %), a 5-slot ring (+-1 %), persistent workgroups (+-1 %).
 #include <stdlib.h>
 #include "glc_common.h"
 #include "glc_kernels.h"

@@ -56,11 +56,12 @@ for tag, corr in (("fetch", 2.0), ("write", 1.0)):
 
 # bench.py reads this (committed as profiles/traffic.json) for roofline.traffic of its dominant kernel class
 import json
-cls = {"attention": "attn_band_kernel", "gemm_ffn1_gelu": "gemm256_kernelIDF16_Li1ELb0", "gemm_qkv": "gemm256_kernelIDF16_Li3ELb0"}
+cls = {"attention": r"attn_band_kernel", "gemm_ffn1_gelu": r"gemm256s?_kernelIDF16_Li1ELb0", "gemm_qkv": r"gemm256s?_kernelIDF16_Li3ELb0",
+       "gemm_ffn2": r"gemm256s?_kernelIDF16_Li2ELb0"}
 outj = {}
 for c, pat in cls.items():
     for name, v in traffic.items():
-        if pat in name and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
+        if re.search(pat, name) and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
             outj[c] = dict(kernel=name, hbm_bytes_per_launch=v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], **v)
 json.dump(dict(source=os.path.basename(out.rstrip("/")), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH x2 (gfx950)", kernels=outj),
           open(os.path.join(out, "traffic.json"), "w"), indent=1)

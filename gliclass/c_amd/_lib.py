@@ -18,7 +18,8 @@ class ModelConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("vocab", "hidden", "layers", "heads", "head_dim", "inter", "pos_buckets",
                                          "max_rel_pos", "pad_id", "cls_id", "sep_id", "class_token_index",
                                          "text_token_index", "pooling", "scorer", "embed_class_token",
-                                         "normalize_features")] + [("ln_eps", C.c_float), ("logit_scale", C.c_float)]
+                                         "normalize_features", "backbone", "kv_heads", "causal")] + \
+               [("ln_eps", C.c_float), ("logit_scale", C.c_float), ("rope_theta", C.c_float)]
 
 
 class Weights(C.Structure):

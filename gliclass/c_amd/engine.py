@@ -15,7 +15,8 @@ DTYPE_NAMES = {v: k for k, v in DTYPES.items()}
 def to_c_config(cfg: GLiClassConfig) -> _lib.ModelConfig:
     return _lib.ModelConfig(cfg.vocab, cfg.hidden, cfg.layers, cfg.heads, cfg.head_dim, cfg.inter, cfg.pos_buckets,
                             cfg.max_rel_pos, cfg.pad_id, cfg.cls_id, cfg.sep_id, cfg.class_token_index, cfg.text_token_index,
-                            cfg.pooling, cfg.scorer, cfg.embed_class_token, cfg.normalize_features, cfg.ln_eps, cfg.logit_scale)
+                            cfg.pooling, cfg.scorer, cfg.embed_class_token, cfg.normalize_features, cfg.backbone, cfg.kv_heads,
+                            cfg.causal, cfg.ln_eps, cfg.logit_scale, cfg.rope_theta)
 
 
 def delta_table(S, bucket_size=256, max_position=512):

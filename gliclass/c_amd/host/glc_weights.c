@@ -50,7 +50,24 @@ int glc_named_config(const char* name, glc_model_config* c) {
             c->pad_id = 0; c->cls_id = 1; c->sep_id = 2;
             c->class_token_index = c->vocab - 2; c->text_token_index = c->vocab - 1;
             c->pooling = GLC_POOL_FIRST; c->scorer = GLC_SCORER_DOT; c->embed_class_token = 1; c->normalize_features = 0;
+            c->backbone = GLC_BACKBONE_DEBERTA; c->kv_heads = c->heads; c->causal = 1; c->rope_theta = 1.0e6f;
             c->ln_eps = 1e-7f; c->logit_scale = 1.0f;
+            return 0;
+        }
+    /* decoder-style backbones (config.py CONFIGS "dec-tiny", "dec-mini", "qwen-1.5b") */
+    static const struct { const char* n; int vocab, hidden, layers, heads, kv, inter; } D[] = {
+        {"dec-tiny", 515, 256, 2, 2, 1, 512}, {"dec-mini", 1027, 512, 3, 4, 2, 768}, {"qwen-1.5b", 151648, 1536, 28, 12, 2, 8960},
+    };
+    for (size_t i = 0; i < sizeof(D) / sizeof(D[0]); ++i)
+        if (strcmp(name, D[i].n) == 0) {
+            memset(c, 0, sizeof(*c));
+            c->vocab = D[i].vocab; c->hidden = D[i].hidden; c->layers = D[i].layers; c->heads = D[i].heads;
+            c->head_dim = 128; c->inter = D[i].inter; c->pos_buckets = 256; c->max_rel_pos = 512;
+            c->pad_id = 0; c->cls_id = 1; c->sep_id = 2;
+            c->class_token_index = c->vocab - 2; c->text_token_index = c->vocab - 1;
+            c->pooling = GLC_POOL_LAST; c->scorer = GLC_SCORER_DOT; c->embed_class_token = 1; c->normalize_features = 0;
+            c->backbone = GLC_BACKBONE_DECODER; c->kv_heads = D[i].kv; c->causal = 1; c->rope_theta = 1.0e6f;
+            c->ln_eps = 1e-6f; c->logit_scale = 1.0f;
             return 0;
         }
     return -1;
@@ -65,6 +82,44 @@ int glc_tensor_spec(const glc_model_config* c, int i, char* name, uint64_t shape
     *mean = 0.0;
 #define SPEC1(nm, n0, a, m) do { snprintf(name, 96, "%s", nm); shape[0] = (n0); *amp = (a); *mean = (m); return 1; } while (0)
 #define SPEC2(nm, n0, n1, a) do { snprintf(name, 96, "%s", nm); shape[0] = (n0); shape[1] = (n1); *amp = (a); return 2; } while (0)
+    if (c->backbone == GLC_BACKBONE_DECODER) {
+        const uint64_t nqd = (uint64_t)c->heads * (uint64_t)c->head_dim;
+        const uint64_t nkvd = (uint64_t)(c->kv_heads > 0 ? c->kv_heads : c->heads) * (uint64_t)c->head_dim;
+        const int nl = GLC_DEC_TENSORS_PER_LAYER * c->layers;
+        char buf[96];
+        if (i == 0) SPEC2("embed_tokens.weight", (uint64_t)c->vocab, H, 1.0);
+        if (i >= 1 && i < 1 + nl) {
+            const int l = (i - 1) / GLC_DEC_TENSORS_PER_LAYER, k = (i - 1) % GLC_DEC_TENSORS_PER_LAYER;
+            static const char* sfx[12] = {
+                "input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias", "self_attn.o_proj.weight",
+                "post_attention_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"};
+            snprintf(buf, sizeof buf, "layers.%d.%s", l, sfx[k]);
+            switch (k) {
+                case 0: case 8: SPEC1(buf, H, 0.2, 1.0);
+                case 1: SPEC2(buf, nqd, H, lin_amp(1.6, (double)H));
+                case 2: SPEC1(buf, nqd, 0.1, 0.0);
+                case 3: SPEC2(buf, nkvd, H, lin_amp(1.6, (double)H));
+                case 4: case 6: SPEC1(buf, nkvd, 0.1, 0.0);
+                case 5: SPEC2(buf, nkvd, H, lin_amp(1.0, (double)H));
+                case 7: SPEC2(buf, H, nqd, lin_amp(0.7, (double)nqd));
+                case 9: case 10: SPEC2(buf, I, H, lin_amp(1.0, (double)H));
+                default: SPEC2(buf, H, I, lin_amp(0.7, (double)I));
+            }
+        }
+        if (i == 1 + nl) SPEC1("norm.weight", H, 0.2, 1.0);
+        const int k = i - 2 - nl;
+        if (k < 0 || k >= GLC_TENSORS_HEAD) return -1;
+        const double t2 = sqrt(1.5 / sqrt((double)H)) / 0.7;
+        snprintf(buf, sizeof buf, "%s.linear_%d.%s", k < 4 ? "text_projector" : "classes_projector", (k % 4) / 2 + 1,
+                 (k % 2) ? "bias" : "weight");
+        switch (k % 4) {
+            case 0: SPEC2(buf, H, H, lin_amp(1.0, (double)H));
+            case 1: SPEC1(buf, H, 0.1, 0.0);
+            case 2: SPEC2(buf, H, H, lin_amp(t2, (double)H));
+            default: SPEC1(buf, H, 0.02, 0.0);
+        }
+    }
     switch (i) {
         case 0: SPEC2("embeddings.word_embeddings.weight", (uint64_t)c->vocab, H, 1.0);
         case 1: SPEC1("embeddings.LayerNorm.weight", H, 0.2, 1.0);
@@ -121,7 +176,7 @@ static int load_synthetic(const char* spec, glc_weights* w) {
     name[nlen] = 0;
     if (colon) seed = strtoull(colon + 1, NULL, 10);
     if (glc_named_config(name, &w->cfg) != 0) { fprintf(stderr, "Error: unknown synthetic config '%s'\n", name); return -1; }
-    w->n_tensors = glc_num_tensors(w->cfg.layers);
+    w->n_tensors = glc_num_tensors_cfg(&w->cfg);
     w->tensors = (const float**)calloc((size_t)w->n_tensors, sizeof(float*));
     if (!w->tensors) return -1;
     size_t total = 0;
@@ -163,8 +218,8 @@ static int load_blob(const char* path, glc_weights* w) {
     uint32_t ver, nt;
     memcpy(&ver, b + 8, 4);
     memcpy(&nt, b + 12, 4);
-    int32_t ints[17];
-    float fl[2];
+    int32_t ints[20];
+    float fl[3];
     memcpy(ints, b + 16, sizeof ints);
     memcpy(fl, b + 16 + sizeof ints, sizeof fl);
     glc_model_config* c = &w->cfg;
@@ -172,8 +227,9 @@ static int load_blob(const char* path, glc_weights* w) {
     c->pos_buckets = ints[6]; c->max_rel_pos = ints[7]; c->pad_id = ints[8]; c->cls_id = ints[9]; c->sep_id = ints[10];
     c->class_token_index = ints[11]; c->text_token_index = ints[12]; c->pooling = ints[13]; c->scorer = ints[14];
     c->embed_class_token = ints[15]; c->normalize_features = ints[16];
-    c->ln_eps = fl[0]; c->logit_scale = fl[1];
-    if (ver != 1 || c->layers <= 0 || c->layers > 4096 || (int)nt != glc_num_tensors(c->layers)) {
+    c->backbone = ints[17]; c->kv_heads = ints[18]; c->causal = ints[19];
+    c->ln_eps = fl[0]; c->logit_scale = fl[1]; c->rope_theta = fl[2];
+    if (ver != 2 || c->layers <= 0 || c->layers > 4096 || (int)nt != glc_num_tensors_cfg(c)) {
         fprintf(stderr, "Error: '%s': unsupported GLCW header (version %u, %u tensors)\n", path, ver, nt);
         return -1;
     }

@@ -16,7 +16,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from .config import GLiClassConfig
+from .config import GLiClassConfig, BACKBONE_DECODER
 from . import prng
 
 MAGIC = b"GLCW\x00\x01\x00\x00"
@@ -25,8 +25,8 @@ TENSOR_REC_BYTES = 160
 # int32 slots of the header, in order (mirrors struct glcw_header in include/gliclass_hip.h)
 _INT_FIELDS = ["vocab", "hidden", "layers", "heads", "head_dim", "inter", "pos_buckets", "max_rel_pos",
                "pad_id", "cls_id", "sep_id", "class_token_index", "text_token_index",
-               "pooling", "scorer", "embed_class_token", "normalize_features"]
-_F32_FIELDS = ["ln_eps", "logit_scale"]
+               "pooling", "scorer", "embed_class_token", "normalize_features", "backbone", "kv_heads", "causal"]
+_F32_FIELDS = ["ln_eps", "logit_scale", "rope_theta"]
 
 
 def tensor_specs(cfg: GLiClassConfig) -> List[Tuple[str, Tuple[int, ...], float, float]]:
@@ -41,6 +41,41 @@ def tensor_specs(cfg: GLiClassConfig) -> List[Tuple[str, Tuple[int, ...], float,
 
     def lin(t, fan_in):
         return s3 * t / math.sqrt(fan_in)
+
+    def head_specs():
+        t2 = math.sqrt(1.5 / math.sqrt(H)) / 0.7
+        out = []
+        for proj in ("text_projector", "classes_projector"):
+            out += [
+                (proj + ".linear_1.weight", (H, H), lin(1.0, H), 0.0),
+                (proj + ".linear_1.bias", (H,), 0.1, 0.0),
+                (proj + ".linear_2.weight", (H, H), lin(t2, H), 0.0),
+                (proj + ".linear_2.bias", (H,), 0.02, 0.0),
+            ]
+        return out
+
+    if cfg.backbone == BACKBONE_DECODER:
+        # HF Qwen2Model.state_dict() names (prefix-free).  q/k amplitudes give score std ~ 2-3 after 1/sqrt(d).
+        nqd, nkvd = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+        specs = [("embed_tokens.weight", (cfg.vocab, H), 1.0, 0.0)]
+        for i in range(L):
+            p = f"layers.{i}."
+            specs += [
+                (p + "input_layernorm.weight", (H,), 0.2, 1.0),
+                (p + "self_attn.q_proj.weight", (nqd, H), lin(1.6, H), 0.0),
+                (p + "self_attn.q_proj.bias", (nqd,), 0.1, 0.0),
+                (p + "self_attn.k_proj.weight", (nkvd, H), lin(1.6, H), 0.0),
+                (p + "self_attn.k_proj.bias", (nkvd,), 0.1, 0.0),
+                (p + "self_attn.v_proj.weight", (nkvd, H), lin(1.0, H), 0.0),
+                (p + "self_attn.v_proj.bias", (nkvd,), 0.1, 0.0),
+                (p + "self_attn.o_proj.weight", (H, nqd), lin(0.7, nqd), 0.0),
+                (p + "post_attention_layernorm.weight", (H,), 0.2, 1.0),
+                (p + "mlp.gate_proj.weight", (I, H), lin(1.0, H), 0.0),
+                (p + "mlp.up_proj.weight", (I, H), lin(1.0, H), 0.0),
+                (p + "mlp.down_proj.weight", (H, I), lin(0.7, I), 0.0),
+            ]
+        specs += [("norm.weight", (H,), 0.2, 1.0)]
+        return specs + head_specs()
 
     specs = [
         ("embeddings.word_embeddings.weight", (cfg.vocab, H), 1.0, 0.0),
@@ -70,15 +105,7 @@ def tensor_specs(cfg: GLiClassConfig) -> List[Tuple[str, Tuple[int, ...], float,
             (p + "output.LayerNorm.weight", (H,), 0.2, 1.0),
             (p + "output.LayerNorm.bias", (H,), 0.1, 0.0),
         ]
-    t2 = math.sqrt(1.5 / math.sqrt(H)) / 0.7
-    for proj in ("text_projector", "classes_projector"):
-        specs += [
-            (proj + ".linear_1.weight", (H, H), lin(1.0, H), 0.0),
-            (proj + ".linear_1.bias", (H,), 0.1, 0.0),
-            (proj + ".linear_2.weight", (H, H), lin(t2, H), 0.0),
-            (proj + ".linear_2.bias", (H,), 0.02, 0.0),
-        ]
-    return specs
+    return specs + head_specs()
 
 
 def make_weights(cfg: GLiClassConfig, seed: int = 42) -> Dict[str, np.ndarray]:
@@ -91,7 +118,7 @@ def make_weights(cfg: GLiClassConfig, seed: int = 42) -> Dict[str, np.ndarray]:
 
 def _pack_header(cfg: GLiClassConfig, n_tensors: int) -> bytes:
     d = cfg.asdict()
-    b = MAGIC + struct.pack("<II", 1, n_tensors)
+    b = MAGIC + struct.pack("<II", 2, n_tensors)     # version 2: + backbone, kv_heads, causal, rope_theta
     b += struct.pack("<%di" % len(_INT_FIELDS), *[int(d[k]) for k in _INT_FIELDS])
     b += struct.pack("<%df" % len(_F32_FIELDS), *[float(d[k]) for k in _F32_FIELDS])
     assert len(b) <= HEADER_BYTES
@@ -130,7 +157,9 @@ def read_blob(path: str) -> Tuple[GLiClassConfig, Dict[str, np.ndarray]]:
     hdr = raw[:HEADER_BYTES].tobytes()
     if hdr[:8] != MAGIC:
         raise ValueError("not a GLCW blob")
-    _, n_t = struct.unpack_from("<II", hdr, 8)
+    ver, n_t = struct.unpack_from("<II", hdr, 8)
+    if ver != 2:
+        raise ValueError(f"unsupported GLCW version {ver}")
     ints = struct.unpack_from("<%di" % len(_INT_FIELDS), hdr, 16)
     flts = struct.unpack_from("<%df" % len(_F32_FIELDS), hdr, 16 + 4 * len(_INT_FIELDS))
     kw = dict(zip(_INT_FIELDS, ints))
@@ -154,7 +183,7 @@ def from_state_dict(sd: Dict[str, "np.ndarray"], cfg: GLiClassConfig) -> Dict[st
     out = {}
     want = [s[0] for s in tensor_specs(cfg)]
     for n in want:
-        for pre in ("", "deberta.", "encoder_model.model.", "model.encoder_model.model.", "model."):
+        for pre in ("", "deberta.", "encoder_model.model.", "model.encoder_model.model.", "model.", "decoder_model.model."):
             if pre + n in sd:
                 v = sd[pre + n]
                 out[n] = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, np.float32)

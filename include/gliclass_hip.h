@@ -29,15 +29,20 @@ extern "C" {
 /* arithmetic type of the GEMM/attention operands (accumulation, LayerNorm statistics, softmax and
  * the scorer head are always fp32) */
 enum { GLC_F32 = 0, GLC_BF16 = 1, GLC_F16 = 2 };
-enum { GLC_POOL_FIRST = 0, GLC_POOL_AVG = 1 };
+enum { GLC_POOL_FIRST = 0, GLC_POOL_AVG = 1, GLC_POOL_LAST = 2 /* last attended token (decoder backbones) */ };
 enum { GLC_SCORER_DOT = 0 };
+/* backbone family: DeBERTa-v2/v3 disentangled encoder, or a decoder-style stack with Qwen2 arithmetic (RMSNorm, RoPE,
+ * grouped-query attention, SwiGLU; SURVEY.md §8a row a16, BASELINE.json configs[4]) */
+enum { GLC_BACKBONE_DEBERTA = 0, GLC_BACKBONE_DECODER = 1 };
 
 /* Same int/float slots, same order, as the .glcw blob header (gliclass/c_amd/weights.py). */
 typedef struct glc_model_config {
     int32_t vocab, hidden, layers, heads, head_dim, inter, pos_buckets, max_rel_pos;
     int32_t pad_id, cls_id, sep_id, class_token_index, text_token_index;
     int32_t pooling, scorer, embed_class_token, normalize_features;
-    float ln_eps, logit_scale;
+    int32_t backbone, kv_heads, causal;    /* decoder backbone: key/value heads (0 = heads), causal mask on/off */
+    float ln_eps, logit_scale;             /* ln_eps is rms_norm_eps for the decoder backbone */
+    float rope_theta;
 } glc_model_config;
 
 /* Tensor order expected in `tensors[]` (all fp32, row-major, nn.Linear weights are [out,in]):
@@ -50,6 +55,16 @@ typedef struct glc_model_config {
 #define GLC_TENSORS_PER_LAYER 16
 #define GLC_TENSORS_HEAD 8
 static inline int glc_num_tensors(int layers) { return GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * layers + GLC_TENSORS_HEAD; }
+/* Decoder backbone (names of HF Qwen2Model.state_dict()):
+ *   0 embed_tokens.weight [vocab,H]
+ *   1+12*l .. : layer l: input_layernorm.weight  q_proj.{w,b} [nq*d,H]  k_proj.{w,b} [nkv*d,H]  v_proj.{w,b}
+ *                        o_proj.weight [H,nq*d]  post_attention_layernorm.weight
+ *                        mlp.gate_proj.weight [I,H]  mlp.up_proj.weight [I,H]  mlp.down_proj.weight [H,I]
+ *   then norm.weight [H], then the same 8 head tensors */
+#define GLC_DEC_TENSORS_PER_LAYER 12
+static inline int glc_num_tensors_cfg(const glc_model_config* c) {
+    return c->backbone == GLC_BACKBONE_DECODER ? 2 + GLC_DEC_TENSORS_PER_LAYER * c->layers + GLC_TENSORS_HEAD : glc_num_tensors(c->layers);
+}
 
 typedef struct glc_engine glc_engine;
 

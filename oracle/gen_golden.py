@@ -1,6 +1,6 @@
-"""ORACLE tooling — regenerates tests/golden/*.npz from HuggingFace DebertaV2Model (fp32, CPU).
+"""ORACLE tooling — regenerates tests/golden/*.npz from HuggingFace DebertaV2Model / Qwen2Model (fp32, CPU).
 
-Run in the build container:  python oracle/gen_golden.py
+Run in the build container:  python oracle/gen_golden.py [case-name prefix]      (e.g. `dec_` for the decoder cases only)
 The fixtures are *data* (inputs + expected outputs); weights are not stored — they are
 reproduced from (config name, seed) by gliclass.c_amd.weights.make_weights on every side.
 
@@ -39,6 +39,10 @@ CASES = [
     ("mini_b4_s128", "mini", 4, 128, 4, True, [4, 4, 1, 3]),
     ("mini_b2_s333", "mini", 2, 333, 2, True, None),
     ("small_c1_b1_s128", "small", 1, 128, 4, False, None),   # BASELINE.json configs[0] shape
+    # decoder-style backbone (BASELINE.json configs[4] arithmetic: RoPE, grouped-query causal attention, SwiGLU, RMSNorm)
+    ("dec_tiny_b3_s200", "dec-tiny", 3, 200, 4, True, [4, 2, 3]),
+    ("dec_tiny_b2_s700", "dec-tiny", 2, 700, 5, True, [5, 1]),
+    ("dec_mini_b2_s333", "dec-mini", 2, 333, 3, True, None),
 ]
 
 
@@ -48,6 +52,7 @@ def sample_positions(S):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     os.makedirs(OUT, exist_ok=True)
     meta = dict(transformers=transformers.__version__, torch=torch.__version__, weight_seed=WEIGHT_SEED)
     # 1) relative-position tables, straight from HF's jit-scripted float32 function
@@ -56,10 +61,13 @@ def main():
         rel = torch.arange(-(S - 1), S, dtype=torch.long)
         b = make_log_bucket_position(rel, 256, 512).to(torch.long)
         tabs[f"S{S}"] = torch.clamp(b + 256, 0, 511).numpy().astype(np.int16)
-    np.savez_compressed(os.path.join(OUT, "delta_tables.npz"), **tabs)
+    if not only:
+        np.savez_compressed(os.path.join(OUT, "delta_tables.npz"), **tabs)
 
     models = {}
     for name, cname, B, S, C, ragged, lpr in CASES:
+        if not name.startswith(only):
+            continue
         cfg = CONFIGS[cname]
         if cname not in models:
             w = weights.make_weights(cfg, WEIGHT_SEED)

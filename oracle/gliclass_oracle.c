@@ -15,6 +15,11 @@
  * fixtures in tests/golden (made by oracle/gen_golden.py); the head is "parity unpinned"
  * (no gliclass package / no golden logits available offline — SURVEY.md §8c).
  *
+ * glo_forward_decoder restates the decoder-style backbone of BASELINE.json configs[4] after
+ * transformers' models/qwen2/modeling_qwen2.py — cited below as Q2:<line>; pinned against Qwen2Model through
+ * tests/golden/dec_*.npz (causal mask).  The bidirectional variant (causal = 0) and the head on top of a decoder are
+ * "parity unpinned" (upstream gliclass wraps decoders itself; package unavailable).
+ *
  * The formulation is deliberately the LITERAL one of the HF code (dense c2p/p2c score matrices,
  * gather by clamp(rel+span), masked_fill(finfo.min), division by sqrt(3d)) so that it is an
  * independent check of the re-derived Toeplitz/band formulation the HIP kernels use.
@@ -33,6 +38,9 @@ typedef struct {
     int32_t vocab, hidden, layers, heads, head_dim, inter, pos_buckets, max_rel_pos;
     int32_t pad_id, class_token_index, embed_class_token, pooling, normalize_features;
     float ln_eps, logit_scale;
+    /* decoder backbone (glo_forward_decoder): key/value heads, causal flag, RoPE base; ln_eps = rms_norm_eps */
+    int32_t backbone, kv_heads, causal;
+    float rope_theta;
 } glo_config;
 
 /* tensor order = gliclass/c_amd/weights.py::tensor_specs */
@@ -120,6 +128,68 @@ static void layernorm_rows(const float* X, int M, int H, const float* g, const f
 }
 
 static inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+/* ---- GLiClass head (parity unpinned): X [B,S,H] final hidden states -> logits ---- */
+static void glo_head(const glo_config* cfg, const float* const* hw, const float* X, const int64_t* ids, const int64_t* mask,
+                     int B, int S, float* logits, int c_alloc, int* c_out) {
+    const int H = cfg->hidden;
+    int C = 0;
+    for (int b = 0; b < B; ++b) {
+        int c = 0;
+        for (int s = 0; s < S; ++s) c += ids[(size_t)b * S + s] == cfg->class_token_index;
+        if (c > C) C = c;
+    }
+    if (c_out) *c_out = C;
+    if (C > c_alloc) C = c_alloc;
+    int rows = B * (1 + C);
+    float* G = (float*)calloc((size_t)rows * H, sizeof(float));
+    float* G1 = (float*)malloc((size_t)rows * H * sizeof(float));
+    float* G2 = (float*)malloc((size_t)rows * H * sizeof(float));
+    for (int b = 0; b < B; ++b) {
+        float* pooled = G + (size_t)b * H;
+        if (cfg->pooling == 0) memcpy(pooled, X + (size_t)b * S * H, (size_t)H * sizeof(float));
+        else if (cfg->pooling == 2) {          /* last attended token (decoder backbones) */
+            int last = 0;
+            for (int s = 0; s < S; ++s) if (mask[(size_t)b * S + s]) last = s;
+            memcpy(pooled, X + ((size_t)b * S + last) * H, (size_t)H * sizeof(float));
+        } else {
+            for (int s = 0; s < S; ++s)
+                for (int i = 0; i < H; ++i) pooled[i] += X[((size_t)b * S + s) * H + i];
+            for (int i = 0; i < H; ++i) pooled[i] /= (float)S;
+        }
+        int j = 0;
+        for (int s = 0; s < S && j < C; ++s)
+            if (ids[(size_t)b * S + s] == cfg->class_token_index) {
+                int pos = cfg->embed_class_token ? s : (s + 1 < S ? s + 1 : s);
+                memcpy(G + ((size_t)B + (size_t)b * C + j) * H, X + ((size_t)b * S + pos) * H, (size_t)H * sizeof(float));
+                ++j;
+            }
+    }
+    /* text projector on rows [0,B), classes projector on rows [B, B+B*C) */
+    linear(G, B, H, hw[H_T1W], hw[H_T1B], H, G1);
+    for (size_t i = 0; i < (size_t)B * H; ++i) G1[i] = gelu_erf(G1[i]);
+    linear(G1, B, H, hw[H_T2W], hw[H_T2B], H, G2);
+    if (C > 0) {
+        linear(G + (size_t)B * H, B * C, H, hw[H_C1W], hw[H_C1B], H, G1 + (size_t)B * H);
+        for (size_t i = (size_t)B * H; i < (size_t)rows * H; ++i) G1[i] = gelu_erf(G1[i]);
+        linear(G1 + (size_t)B * H, B * C, H, hw[H_C2W], hw[H_C2B], H, G2 + (size_t)B * H);
+    }
+    if (cfg->normalize_features)
+        for (int r = 0; r < rows; ++r) {
+            float nn = 0;
+            for (int i = 0; i < H; ++i) nn += G2[(size_t)r * H + i] * G2[(size_t)r * H + i];
+            nn = sqrtf(nn) + 1e-8f;
+            for (int i = 0; i < H; ++i) G2[(size_t)r * H + i] /= nn;
+        }
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < C; ++j) {
+            float a = 0;
+            for (int i = 0; i < H; ++i) a += G2[(size_t)b * H + i] * G2[((size_t)B + (size_t)b * C + j) * H + i];
+            if (cfg->normalize_features) a *= cfg->logit_scale;
+            logits[(size_t)b * c_alloc + j] = a;
+        }
+    free(G); free(G1); free(G2);
+}
 
 /*
  * One forward.  tensors[] in tensor_specs order.  logits: [B, c_alloc] row-major with stride
@@ -244,63 +314,152 @@ int glo_forward(const glo_config* cfg, const float* const* tensors, const int64_
         if (hidden_dump) memcpy(hidden_dump + (size_t)(l + 1) * M * H, X, (size_t)M * H * sizeof(float));
     }
 
-    /* ---- GLiClass uni-encoder head (parity unpinned) ---- */
-    const float* const* hw = tensors + T_LAYER0 + L * L_N;
-    int C = 0;
-    for (int b = 0; b < B; ++b) {
-        int c = 0;
-        for (int s = 0; s < S; ++s) c += ids[(size_t)b * S + s] == cfg->class_token_index;
-        if (c > C) C = c;
-    }
-    if (c_out) *c_out = C;
-    if (C > c_alloc) C = c_alloc;
-    int rows = B * (1 + C);
-    float* G = (float*)calloc((size_t)rows * H, sizeof(float));
-    float* G1 = (float*)malloc((size_t)rows * H * sizeof(float));
-    float* G2 = (float*)malloc((size_t)rows * H * sizeof(float));
-    for (int b = 0; b < B; ++b) {
-        float* pooled = G + (size_t)b * H;
-        if (cfg->pooling == 0) memcpy(pooled, X + (size_t)b * S * H, (size_t)H * sizeof(float));
-        else {
-            for (int s = 0; s < S; ++s)
-                for (int i = 0; i < H; ++i) pooled[i] += X[((size_t)b * S + s) * H + i];
-            for (int i = 0; i < H; ++i) pooled[i] /= (float)S;
-        }
-        int j = 0;
-        for (int s = 0; s < S && j < C; ++s)
-            if (ids[(size_t)b * S + s] == cfg->class_token_index) {
-                int pos = cfg->embed_class_token ? s : (s + 1 < S ? s + 1 : s);
-                memcpy(G + ((size_t)B + (size_t)b * C + j) * H, X + ((size_t)b * S + pos) * H, (size_t)H * sizeof(float));
-                ++j;
-            }
-    }
-    /* text projector on rows [0,B), classes projector on rows [B, B+B*C) */
-    linear(G, B, H, hw[H_T1W], hw[H_T1B], H, G1);
-    for (size_t i = 0; i < (size_t)B * H; ++i) G1[i] = gelu_erf(G1[i]);
-    linear(G1, B, H, hw[H_T2W], hw[H_T2B], H, G2);
-    if (C > 0) {
-        linear(G + (size_t)B * H, B * C, H, hw[H_C1W], hw[H_C1B], H, G1 + (size_t)B * H);
-        for (size_t i = (size_t)B * H; i < (size_t)rows * H; ++i) G1[i] = gelu_erf(G1[i]);
-        linear(G1 + (size_t)B * H, B * C, H, hw[H_C2W], hw[H_C2B], H, G2 + (size_t)B * H);
-    }
-    if (cfg->normalize_features)
-        for (int r = 0; r < rows; ++r) {
-            float nn = 0;
-            for (int i = 0; i < H; ++i) nn += G2[(size_t)r * H + i] * G2[(size_t)r * H + i];
-            nn = sqrtf(nn) + 1e-8f;
-            for (int i = 0; i < H; ++i) G2[(size_t)r * H + i] /= nn;
-        }
-    for (int b = 0; b < B; ++b)
-        for (int j = 0; j < C; ++j) {
-            float a = 0;
-            for (int i = 0; i < H; ++i) a += G2[(size_t)b * H + i] * G2[((size_t)B + (size_t)b * C + j) * H + i];
-            if (cfg->normalize_features) a *= cfg->logit_scale;
-            logits[(size_t)b * c_alloc + j] = a;
-        }
-    free(G); free(G1); free(G2);
+    glo_head(cfg, tensors + T_LAYER0 + L * L_N, X, ids, mask, B, S, logits, c_alloc, c_out);
     free(X); free(Q); free(Kb); free(V); free(CTX); free(T1); free(H1); free(FF); free(R); free(PK); free(PQ); free(dtab);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Decoder-style backbone (Qwen2 arithmetic).  tensors[]: embed_tokens, per layer {input_layernorm, q.w q.b k.w k.b v.w v.b,
+ * o.w, post_attention_layernorm, gate.w up.w down.w}, norm, then the 8 head tensors (weights.py::tensor_specs).
+ * hidden_dump (optional): [(L+1),B,S,H] = embeddings, output of layers 0..L-2, and norm(output of layer L-1) — the
+ * tuple HF returns with output_hidden_states=True.
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { D_LN1 = 0, D_QW, D_QB, D_KW, D_KB, D_VW, D_VB, D_OW, D_LN2, D_GW, D_UW, D_DW, D_N };
+
+/* Q2:247-252 */
+static void rmsnorm_rows(const float* X, int M, int H, const float* w, float eps, float* Y) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        const float* x = X + (size_t)m * H;
+        float* y = Y + (size_t)m * H;
+        double ss = 0;
+        for (int i = 0; i < H; ++i) ss += (double)x[i] * x[i];
+        float r = 1.0f / sqrtf((float)(ss / H) + eps);
+        for (int i = 0; i < H; ++i) y[i] = w[i] * (x[i] * r);
+    }
+}
+
+int glo_forward_decoder(const glo_config* cfg, const float* const* tensors, const int64_t* ids, const int64_t* mask,
+                        int B, int S, float* logits, int c_alloc, int* c_out, float* hidden_dump) {
+    const int H = cfg->hidden, nq = cfg->heads, d = cfg->head_dim, I = cfg->inter, L = cfg->layers;
+    const int nkv = cfg->kv_heads > 0 ? cfg->kv_heads : nq, grp = nq / nkv, NQ = nq * d, NKV = nkv * d, hd2 = d / 2;
+    const int M = B * S;
+    if (NQ != H && 0) return -1;
+    if (nq % nkv || d % 2) return -1;
+    float* X = (float*)malloc((size_t)M * H * sizeof(float));
+    float* Hn = (float*)malloc((size_t)M * H * sizeof(float));
+    float* Q = (float*)malloc((size_t)M * NQ * sizeof(float));
+    float* Kb = (float*)malloc((size_t)M * NKV * sizeof(float));
+    float* V = (float*)malloc((size_t)M * NKV * sizeof(float));
+    float* CTX = (float*)malloc((size_t)M * NQ * sizeof(float));
+    float* T1 = (float*)malloc((size_t)M * H * sizeof(float));
+    float* G = (float*)malloc((size_t)M * I * sizeof(float));
+    float* U = (float*)malloc((size_t)M * I * sizeof(float));
+    float* cs = (float*)malloc((size_t)S * hd2 * 2 * sizeof(float));
+    if (!X || !Hn || !Q || !Kb || !V || !CTX || !T1 || !G || !U || !cs) return -2;
+
+    /* Q2:384 inputs_embeds = embed_tokens(input_ids) — no mask multiply, no norm */
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        int64_t id = ids[m];
+        if (id < 0 || id >= cfg->vocab) id = cfg->pad_id;
+        memcpy(X + (size_t)m * H, tensors[0] + (size_t)id * H, (size_t)H * sizeof(float));
+    }
+    if (hidden_dump) memcpy(hidden_dump, X, (size_t)M * H * sizeof(float));
+
+    /* Q2:86 inv_freq = 1 / base^(arange(0,d,2)/d) in float32; Q2:97-100 freqs = inv_freq * position, cos/sin (position_ids =
+     * arange(S), independent of padding) */
+    for (int s = 0; s < S; ++s)
+        for (int i = 0; i < hd2; ++i) {
+            float inv = 1.0f / powf(cfg->rope_theta, (float)(2 * i) / (float)d);
+            float f = inv * (float)s;
+            cs[((size_t)s * hd2 + i) * 2] = cosf(f);
+            cs[((size_t)s * hd2 + i) * 2 + 1] = sinf(f);
+        }
+    const float scaling = 1.0f / sqrtf((float)d);   /* Q2:186 */
+
+    for (int l = 0; l < L; ++l) {
+        const float* const* w = tensors + 1 + l * D_N;
+        rmsnorm_rows(X, M, H, w[D_LN1], cfg->ln_eps, Hn);            /* Q2:280 */
+        linear(Hn, M, H, w[D_QW], w[D_QB], NQ, Q);                   /* Q2:206-208 */
+        linear(Hn, M, H, w[D_KW], w[D_KB], NKV, Kb);
+        linear(Hn, M, H, w[D_VW], w[D_VB], NKV, V);
+        /* Q2:105-109,133-134 rotate_half form: out = x*cos + rotate_half(x)*sin, cos/sin duplicated over the two halves */
+#pragma omp parallel for schedule(static)
+        for (int m = 0; m < M; ++m) {
+            const int s = m % S;
+            for (int pass = 0; pass < 2; ++pass) {
+                float* base = pass == 0 ? Q + (size_t)m * NQ : Kb + (size_t)m * NKV;
+                const int nh_ = pass == 0 ? nq : nkv;
+                for (int h = 0; h < nh_; ++h)
+                    for (int i = 0; i < hd2; ++i) {
+                        float c = cs[((size_t)s * hd2 + i) * 2], sn = cs[((size_t)s * hd2 + i) * 2 + 1];
+                        float x1 = base[h * d + i], x2 = base[h * d + i + hd2];
+                        base[h * d + i] = x1 * c - x2 * sn;
+                        base[h * d + i + hd2] = x2 * c + x1 * sn;
+                    }
+            }
+        }
+        /* Q2:160-170 repeat_kv, scores * scaling + mask, softmax fp32, * V; mask = causal AND key-padding (create_causal_mask) */
+#pragma omp parallel
+        {
+            float* row = (float*)malloc((size_t)S * sizeof(float));
+#pragma omp for schedule(dynamic, 1) collapse(2)
+            for (int b = 0; b < B; ++b)
+                for (int h = 0; h < nq; ++h) {
+                    const int kvh = h / grp;
+                    const int64_t* mk = mask + (size_t)b * S;
+                    for (int i = 0; i < S; ++i) {
+                        const float* q = Q + ((size_t)b * S + i) * NQ + h * d;
+                        float mx = -FLT_MAX;
+                        for (int j = 0; j < S; ++j) {
+                            float a;
+                            if ((cfg->causal && j > i) || !mk[j]) a = -FLT_MAX;
+                            else {
+                                const float* k = Kb + ((size_t)b * S + j) * NKV + kvh * d;
+                                a = 0;
+                                for (int e = 0; e < d; ++e) a += q[e] * k[e];
+                                a *= scaling;
+                            }
+                            row[j] = a;
+                            if (a > mx) mx = a;
+                        }
+                        float sum = 0;
+                        for (int j = 0; j < S; ++j) { row[j] = expf(row[j] - mx); sum += row[j]; }
+                        float inv = 1.0f / sum;
+                        float* o = CTX + ((size_t)b * S + i) * NQ + h * d;
+                        for (int e = 0; e < d; ++e) o[e] = 0;
+                        for (int j = 0; j < S; ++j) {
+                            float pv = row[j] * inv;
+                            if (pv == 0.f) continue;
+                            const float* vr = V + ((size_t)b * S + j) * NKV + kvh * d;
+                            for (int e = 0; e < d; ++e) o[e] += pv * vr[e];
+                        }
+                    }
+                }
+            free(row);
+        }
+        linear(CTX, M, NQ, w[D_OW], NULL, H, T1);                    /* Q2:233 o_proj (no bias) */
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < (size_t)M * H; ++i) X[i] += T1[i];    /* Q2:291 */
+        rmsnorm_rows(X, M, H, w[D_LN2], cfg->ln_eps, Hn);            /* Q2:295 */
+        linear(Hn, M, H, w[D_GW], NULL, I, G);                       /* Q2:47 down(silu(gate(x)) * up(x)) */
+        linear(Hn, M, H, w[D_UW], NULL, I, U);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < (size_t)M * I; ++i) { float g = G[i]; G[i] = g / (1.0f + expf(-g)) * U[i]; }
+        linear(G, M, I, w[D_DW], NULL, H, T1);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < (size_t)M * H; ++i) X[i] += T1[i];
+        if (hidden_dump && l + 1 < L) memcpy(hidden_dump + (size_t)(l + 1) * M * H, X, (size_t)M * H * sizeof(float));
+    }
+    rmsnorm_rows(X, M, H, tensors[1 + L * D_N], cfg->ln_eps, Hn);    /* Q2:398 final norm */
+    if (hidden_dump) memcpy(hidden_dump + (size_t)L * M * H, Hn, (size_t)M * H * sizeof(float));
+    glo_head(cfg, tensors + 2 + L * D_N, Hn, ids, mask, B, S, logits, c_alloc, c_out);
+    free(X); free(Hn); free(Q); free(Kb); free(V); free(CTX); free(T1); free(G); free(U); free(cs);
+    return 0;
+}
+
 
 /* /root/reference/src/postprocessor.c:14-16 */
 float glo_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -16,10 +16,33 @@ PARITY STATUS
 import numpy as np
 import torch
 
-from gliclass.c_amd.config import GLiClassConfig, POOL_FIRST, POOL_AVG
+from gliclass.c_amd.config import GLiClassConfig, POOL_FIRST, POOL_AVG, POOL_LAST, BACKBONE_DECODER
+
+
+def build_hf_decoder(cfg: GLiClassConfig, tensors):
+    """Qwen2Model with the blob's tensors (decoder backbone).  HF's Qwen2 is always causal."""
+    from transformers import Qwen2Config, Qwen2Model
+    assert cfg.causal, "transformers' Qwen2Model has no bidirectional mode: causal = 0 is unpinned"
+    hc = Qwen2Config(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+                     num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_heads, intermediate_size=cfg.inter,
+                     max_position_embeddings=32768, rope_theta=cfg.rope_theta, rms_norm_eps=cfg.ln_eps,
+                     attention_dropout=0.0, use_sliding_window=False, tie_word_embeddings=False, pad_token_id=cfg.pad_id,
+                     attn_implementation="eager")
+    assert hc.hidden_size // hc.num_attention_heads == cfg.head_dim
+    with torch.no_grad():
+        m = Qwen2Model(hc).eval()
+        sd = m.state_dict()
+        for k in sd:
+            if k not in tensors:
+                raise KeyError(k)
+            sd[k] = torch.from_numpy(np.asarray(tensors[k])).clone()
+        m.load_state_dict(sd)
+    return m
 
 
 def build_hf_model(cfg: GLiClassConfig, tensors):
+    if cfg.backbone == BACKBONE_DECODER:
+        return build_hf_decoder(cfg, tensors)
     from transformers import DebertaV2Config, DebertaV2Model
     hc = DebertaV2Config(
         vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
@@ -66,6 +89,9 @@ def gliclass_head(cfg: GLiClassConfig, tensors, hidden, ids, mask):
         pooled = hidden[:, 0, :]
     elif cfg.pooling == POOL_AVG:
         pooled = hidden.mean(1)
+    elif cfg.pooling == POOL_LAST:
+        last = torch.stack([torch.nonzero(mask[b]).flatten()[-1] if mask[b].any() else torch.tensor(0) for b in range(B)])
+        pooled = hidden[torch.arange(B), last]
     else:
         raise NotImplementedError
     pooled = features_projector(pooled, t["text_projector.linear_1.weight"], t["text_projector.linear_1.bias"],

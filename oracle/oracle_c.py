@@ -8,7 +8,7 @@ import subprocess
 
 import numpy as np
 
-from gliclass.c_amd.config import GLiClassConfig
+from gliclass.c_amd.config import GLiClassConfig, BACKBONE_DECODER
 from gliclass.c_amd.weights import tensor_specs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -19,7 +19,8 @@ class GloConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("vocab", "hidden", "layers", "heads", "head_dim", "inter",
                                          "pos_buckets", "max_rel_pos", "pad_id", "class_token_index",
                                          "embed_class_token", "pooling", "normalize_features")] + \
-               [("ln_eps", C.c_float), ("logit_scale", C.c_float)]
+               [("ln_eps", C.c_float), ("logit_scale", C.c_float)] + \
+               [(n, C.c_int32) for n in ("backbone", "kv_heads", "causal")] + [("rope_theta", C.c_float)]
 
 
 def build(force=False):
@@ -39,6 +40,9 @@ def lib():
         _lib.glo_forward.restype = C.c_int
         _lib.glo_forward.argtypes = [C.POINTER(GloConfig), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        _lib.glo_forward_decoder.restype = C.c_int
+        _lib.glo_forward_decoder.argtypes = [C.POINTER(GloConfig), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]
         _lib.glo_delta_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib.glo_sigmoid.restype = C.c_float
         _lib.glo_sigmoid.argtypes = [C.c_float]
@@ -49,7 +53,8 @@ def lib():
 def _cfg(cfg: GLiClassConfig) -> GloConfig:
     return GloConfig(cfg.vocab, cfg.hidden, cfg.layers, cfg.heads, cfg.head_dim, cfg.inter, cfg.pos_buckets,
                      cfg.max_rel_pos, cfg.pad_id, cfg.class_token_index, cfg.embed_class_token, cfg.pooling,
-                     cfg.normalize_features, cfg.ln_eps, cfg.logit_scale)
+                     cfg.normalize_features, cfg.ln_eps, cfg.logit_scale, cfg.backbone, cfg.kv_heads, cfg.causal,
+                     cfg.rope_theta)
 
 
 def delta_table(S, bucket_size=256, max_position=512):
@@ -72,9 +77,15 @@ def forward(cfg: GLiClassConfig, tensors, ids, mask, want_hidden=False, want_sco
     scores = np.zeros((S, S), np.float32) if want_scores else None
     c_out = C.c_int(0)
     cc = _cfg(cfg)
-    rc = lib().glo_forward(C.byref(cc), ptrs, ids.ctypes.data, mask.ctypes.data, B, S, logits.ctypes.data, c_alloc,
-                           C.byref(c_out), hidden.ctypes.data if want_hidden else None,
-                           scores.ctypes.data if want_scores else None)
+    if cfg.backbone == BACKBONE_DECODER:
+        if want_scores:
+            raise ValueError("scores dump exists for the encoder backbone only")
+        rc = lib().glo_forward_decoder(C.byref(cc), ptrs, ids.ctypes.data, mask.ctypes.data, B, S, logits.ctypes.data,
+                                       c_alloc, C.byref(c_out), hidden.ctypes.data if want_hidden else None)
+    else:
+        rc = lib().glo_forward(C.byref(cc), ptrs, ids.ctypes.data, mask.ctypes.data, B, S, logits.ctypes.data, c_alloc,
+                               C.byref(c_out), hidden.ctypes.data if want_hidden else None,
+                               scores.ctypes.data if want_scores else None)
     if rc != 0:
         raise RuntimeError(f"glo_forward failed rc={rc}")
     out = [logits[:, :min(c_out.value, c_alloc)]]

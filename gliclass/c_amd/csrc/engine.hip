@@ -43,6 +43,11 @@ enum { PC_SCAN = 0, PC_EMBED, PC_QKV, PC_ATTN, PC_ATTN_OUT, PC_LN, PC_FFN1, PC_F
 const char* const kProfNames[PC_N] = {"scan_rows", "embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm",
                                       "gemm_ffn1_gelu", "gemm_ffn2", "head", "last_layer_pruned"};
 
+struct DecLayerW {                     // decoder-style backbone (decoder.hip)
+    void *Wqkv = nullptr, *Wo = nullptr, *Wgu = nullptr, *Wd = nullptr;       // T: [(nq+2nkv)d, H], [H, nq d], [2I, H] (gate rows | up rows), [H, I]
+    float *bqkv = nullptr, *ln1 = nullptr, *ln2 = nullptr;                    // f32
+};
+
 struct LayerW {
     void *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;       // T
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;       // f32
@@ -62,6 +67,9 @@ struct glc_engine {
     // weights
     void* emb = nullptr; float *eln_g = nullptr, *eln_b = nullptr;
     std::vector<LayerW> layers;
+    std::vector<DecLayerW> dlayers; float* final_norm = nullptr;      // decoder backbone
+    std::map<int, float*> ropes;                                      // Sp -> [Sp][d/2][cos,sin]
+    void *QKV = nullptr, *GU = nullptr, *X2 = nullptr;                // decoder workspace: fused QKV rows, [gate|up] rows, second residual buffer
     float* headw[8] = {nullptr};
     int P = 0;
     // workspace
@@ -147,6 +155,19 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     const glc_model_config& c = e->cfg;
     const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 256);
     const size_t es = esize(e->dtype);
+    const bool dec = c.backbone == GLC_BACKBONE_DECODER;
+    if (Mpad > e->capM && dec) {
+        const size_t nqd = (size_t)c.heads * c.head_dim, nkvd = (size_t)c.kv_heads * c.head_dim;
+        void** bufs[] = {&e->X, &e->X2, &e->H1};
+        for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
+        dfree(e, e->QKV); e->QKV = dmalloc(e, (size_t)Mpad * (nqd + 2 * nkvd) * es); if (!e->QKV) return false;
+        dfree(e, e->CTX); e->CTX = dmalloc(e, (size_t)Mpad * nqd * es); if (!e->CTX) return false;
+        dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false;
+        dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
+        dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
+        e->capM = Mpad;
+        e->hidden_cap = 0;
+    }
     if (Mpad > e->capM) {
         void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
@@ -179,6 +200,25 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         for (float** b : bufs) { dfree(e, *b); *b = (float*)dmalloc(e, (size_t)hr * c.hidden * sizeof(float)); if (!*b) return false; }
         e->capHeadRows = hr;
     }
+    if (dec) {
+        if (!e->ropes.count(Sp)) {
+            // Q2:86 inv_freq = 1 / base^(arange(0,d,2)/d) in float32; Q2:97-100 freqs = inv_freq * position, then cos / sin
+            const int hd2 = c.head_dim / 2;
+            std::vector<float> t((size_t)Sp * hd2 * 2);
+            for (int s = 0; s < Sp; ++s)
+                for (int i = 0; i < hd2; ++i) {
+                    const float inv = 1.0f / powf(c.rope_theta, (float)(2 * i) / (float)c.head_dim);
+                    const float f = inv * (float)s;
+                    t[((size_t)s * hd2 + i) * 2] = cosf(f);
+                    t[((size_t)s * hd2 + i) * 2 + 1] = sinf(f);
+                }
+            float* d = (float*)dmalloc(e, t.size() * sizeof(float), false);
+            if (!d) return false;
+            if (hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { set_err("rope table upload failed"); return false; }
+            e->ropes[Sp] = d;
+        }
+        return true;
+    }
     const int rsel = round_up(B * (1 + (C > 0 ? C : 0)), 256);
     if (rsel > e->capSel) {
         void** bufs[] = {&e->Xs, &e->Qs, &e->CTXs, &e->T1s, &e->H1s};
@@ -209,8 +249,75 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     return true;
 }
 
+// Decoder-style backbone: one launch sequence per batch (Q2:384-398).  Pre-norm residual stream X (operand type T).
+bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, int C, float* d_logits) {
+    const glc_model_config& c = e->cfg;
+    const int H = c.hidden, I = c.inter, nq = c.heads, nkv = c.kv_heads, d = c.head_dim, L = c.layers;
+    const int NQ = nq * d, NQKV = (nq + 2 * nkv) * d;
+    const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 256);
+    hipStream_t st = e->stream;
+    const int dt = e->dtype;
+    const size_t es = esize(dt);
+    const int ccap = e->capC > 0 ? e->capC : 1;
+    if (e->profile) { e->ev_used = 0; }
+    if (e->keep_hidden) {
+        const size_t need = (size_t)(L + 1) * M * H * es;
+        if (need > e->hidden_cap) { dfree(e, e->hidden_dump); e->hidden_dump = dmalloc(e, need); if (!e->hidden_dump) return false; e->hidden_cap = need; }
+    }
+    { Prof p(e, PC_SCAN);
+      KCHK(glc_launch_scan_rows(st, ids, mask, B, S, c.class_token_index, c.embed_class_token, e->klen, e->kfirst, e->cls_pos, e->cls_cnt, ccap), false); }
+    { Prof p(e, PC_EMBED);
+      KCHK(glc_launch_embed_plain(st, dt, ids, mask, e->emb, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
+    if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+    const float qscale = 1.4426950408889634f / sqrtf((float)d);         // Q2:186 scaling, times log2(e) for the exp2 softmax
+    void *X = e->X, *Xn = e->X2;
+    for (int l = 0; l < L; ++l) {
+        const DecLayerW& w = e->dlayers[l];
+        { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln1, c.ln_eps, M, H), false); }                        // Q2:280
+        GemmArgs g;
+        g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H;
+        { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, g), false);                                           // Q2:206-208
+          KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }                          // Q2:211
+        { Prof p(e, PC_ATTN); KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
+        GemmArgs o;
+        o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ;
+        { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false); }                                   // Q2:233, :291
+        std::swap(X, Xn);
+        { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
+        GemmArgs f1;
+        f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
+        { Prof p(e, PC_FFN1); KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, f1), false);                                         // Q2:47 gate | up
+          KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); }
+        GemmArgs f2;
+        f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I;
+        { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false); }
+        std::swap(X, Xn);
+        if (e->keep_hidden && l + 1 < L)
+            HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+    }
+    { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, e->final_norm, c.ln_eps, M, H), false); }                    // Q2:398
+    if (e->keep_hidden) HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)L * M * H * es, e->H1, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+    if (C > 0) {
+        Prof p(e, PC_HEAD);
+        float* Gc = e->Gt + (size_t)round_up(B, 128) * H;
+        KCHK(glc_launch_head_gather(st, dt, e->H1, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C, c.pooling == GLC_POOL_LAST ? e->klen : nullptr), false);
+        const int rt = round_up(B, 128), rc = round_up(B * C, 128);
+        GemmArgs h;
+        h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
+        h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
+        KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
+        h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
+        KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
+        KCHK(glc_launch_head_score(st, e->G2t, e->G2t + (size_t)rt * H, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
+    }
+    HIPCHK(hipGetLastError(), false);
+    e->lastB = B; e->lastS = S; e->lastSp = Sp;
+    return true;
+}
+
 // The launch sequence for one batch.  ids/mask are device pointers.
 bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, int C, float* d_logits) {
+    if (e->cfg.backbone == GLC_BACKBONE_DECODER) return run_forward_decoder(e, ids, mask, B, S, C, d_logits);
     const glc_model_config& c = e->cfg;
     const int H = c.hidden, I = c.inter, nh = c.heads;
     const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 256);
@@ -318,6 +425,62 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     return true;
 }
 
+// Decoder backbone: upload + convert weights.  Fused operands: Wqkv = [q_proj; k_proj; v_proj] rows, Wgu = [gate_proj; up_proj]
+// rows, so each layer runs four GEMMs (Q2:206-208 as one, Q2:233, Q2:47 gate|up as one, down).
+bool create_decoder(glc_engine* e, const float* const* tensors) {
+    const glc_model_config& c = e->cfg;
+    const int H = c.hidden, I = c.inter, L = c.layers, d = c.head_dim;
+    const size_t NQ = (size_t)c.heads * d, NKV = (size_t)c.kv_heads * d, NQKV = NQ + 2 * NKV;
+    const size_t es = esize(e->dtype);
+    if (NQ % 128 || NKV % 64 || NQKV % 128) { set_err("engine_create: decoder projection widths must be multiples of 128"); return false; }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { set_err("stream create failed"); return false; }
+    if (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) { set_err("event create failed"); return false; }
+    size_t stage_n = (size_t)c.vocab * H;
+    if ((size_t)I * H > stage_n) stage_n = (size_t)I * H;
+    if (NQ * H > stage_n) stage_n = NQ * H;
+    float* staging = nullptr;
+    if (hipMalloc((void**)&staging, stage_n * sizeof(float)) != hipSuccess) { set_err("staging alloc failed"); return false; }
+    bool ok = false;
+    do {
+        e->emb = dmalloc(e, (size_t)c.vocab * H * es, false);
+        if (!e->emb || !upload_as(e, tensors[0], (size_t)c.vocab * H, e->emb, staging)) break;
+        e->dlayers.resize(L);
+        std::vector<float> bqkv(NQKV);
+        bool lok = true;
+        for (int l = 0; l < L && lok; ++l) {
+            const float* const* t = tensors + 1 + GLC_DEC_TENSORS_PER_LAYER * l;    // ln1 qw qb kw kb vw vb ow ln2 gw uw dw
+            DecLayerW& w = e->dlayers[l];
+            w.Wqkv = dmalloc(e, NQKV * H * es, false);
+            w.Wo = dmalloc(e, (size_t)H * NQ * es, false);
+            w.Wgu = dmalloc(e, 2 * (size_t)I * H * es, false);
+            w.Wd = dmalloc(e, (size_t)H * I * es, false);
+            if (!w.Wqkv || !w.Wo || !w.Wgu || !w.Wd) { lok = false; break; }
+            lok = upload_as(e, t[1], NQ * H, w.Wqkv, staging) && upload_as(e, t[3], NKV * H, (char*)w.Wqkv + NQ * H * es, staging) &&
+                  upload_as(e, t[5], NKV * H, (char*)w.Wqkv + (NQ + NKV) * H * es, staging) && upload_as(e, t[7], (size_t)H * NQ, w.Wo, staging) &&
+                  upload_as(e, t[9], (size_t)I * H, w.Wgu, staging) && upload_as(e, t[10], (size_t)I * H, (char*)w.Wgu + (size_t)I * H * es, staging) &&
+                  upload_as(e, t[11], (size_t)H * I, w.Wd, staging);
+            if (!lok) break;
+            for (size_t i = 0; i < NQ; ++i) bqkv[i] = t[2][i];
+            for (size_t i = 0; i < NKV; ++i) { bqkv[NQ + i] = t[4][i]; bqkv[NQ + NKV + i] = t[6][i]; }
+            w.bqkv = upload_f32(e, bqkv.data(), NQKV);
+            w.ln1 = upload_f32(e, t[0], H); w.ln2 = upload_f32(e, t[8], H);
+            if (!w.bqkv || !w.ln1 || !w.ln2) { lok = false; break; }
+            if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // bqkv host buffer is reused
+        }
+        if (!lok) break;
+        e->final_norm = upload_f32(e, tensors[1 + GLC_DEC_TENSORS_PER_LAYER * L], H);
+        if (!e->final_norm) break;
+        const float* const* ht = tensors + 2 + GLC_DEC_TENSORS_PER_LAYER * L;
+        bool hok = true;
+        for (int i = 0; i < 8 && hok; ++i) { e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr; }
+        if (!hok) break;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err(std::string("engine_create: ") + hipGetErrorString(hipGetLastError())); break; }
+        ok = true;
+    } while (0);
+    (void)hipFree(staging);
+    return ok;
+}
+
 bool check_shape(const glc_engine* e, int B, int S, int C) {
     if (B <= 0 || S <= 0 || C < 0) { set_err("forward: B and S must be positive, C non-negative"); return false; }
     if ((long long)B * round_up(S, 64) > (1ll << 30)) { set_err("forward: batch too large"); return false; }
@@ -359,11 +522,19 @@ void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out) {
 glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* tensors, int n_tensors, int device, int dtype) {
     if (!cfg || !tensors) { set_err("engine_create: null argument"); return nullptr; }
     if (dtype != GLC_F32 && dtype != GLC_BF16 && dtype != GLC_F16) { set_err("engine_create: bad dtype"); return nullptr; }
-    if (n_tensors != glc_num_tensors(cfg->layers)) { set_err("engine_create: wrong tensor count"); return nullptr; }
+    if (n_tensors != glc_num_tensors_cfg(cfg)) { set_err("engine_create: wrong tensor count"); return nullptr; }
     for (int i = 0; i < n_tensors; ++i) if (!tensors[i]) { set_err("engine_create: null tensor"); return nullptr; }
-    if (cfg->head_dim != 64 || cfg->hidden != cfg->heads * 64) { set_err("engine_create: head_dim must be 64 (all DeBERTa-v3 backbones)"); return nullptr; }
+    const bool dec = cfg->backbone == GLC_BACKBONE_DECODER;
+    if (cfg->backbone != GLC_BACKBONE_DEBERTA && !dec) { set_err("engine_create: unknown backbone"); return nullptr; }
+    if (!dec && (cfg->head_dim != 64 || cfg->hidden != cfg->heads * 64)) { set_err("engine_create: head_dim must be 64 (all DeBERTa-v3 backbones)"); return nullptr; }
+    if (dec && ((cfg->head_dim != 64 && cfg->head_dim != 128) || cfg->heads <= 0 || cfg->kv_heads < 0 ||
+                cfg->heads % (cfg->kv_heads > 0 ? cfg->kv_heads : cfg->heads) || cfg->rope_theta <= 1.f)) {
+        set_err("engine_create: decoder backbone needs head_dim 64 or 128, heads % kv_heads == 0 and rope_theta > 1"); return nullptr;
+    }
     if (cfg->hidden % 128 || cfg->inter % 128) { set_err("engine_create: hidden and intermediate sizes must be multiples of 128"); return nullptr; }
-    if (cfg->pooling != GLC_POOL_FIRST || cfg->scorer != GLC_SCORER_DOT) { set_err("engine_create: only pooling='first' and scorer='simple' are implemented"); return nullptr; }
+    if ((cfg->pooling != GLC_POOL_FIRST && !(dec && cfg->pooling == GLC_POOL_LAST)) || cfg->scorer != GLC_SCORER_DOT) {
+        set_err("engine_create: only pooling='first' (and 'last' on decoder backbones) with scorer='simple' are implemented"); return nullptr;
+    }
     int ndev = glc_device_count();
     if (ndev <= 0) { set_err("engine_create: no HIP device visible (this engine has no CPU path)"); return nullptr; }
     if (device < 0 || device >= ndev) { set_err("engine_create: bad device ordinal"); return nullptr; }
@@ -371,7 +542,12 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
 
     glc_engine* e = new glc_engine();
     e->cfg = *cfg; e->dtype = dtype; e->device = device;
+    if (e->cfg.kv_heads <= 0) e->cfg.kv_heads = e->cfg.heads;
     if (const char* pv = getenv("GLICLASS_PRUNE_LAST")) e->prune_last = atoi(pv) != 0;
+    if (dec) {
+        if (!create_decoder(e, tensors)) { glc_engine_destroy(e); return nullptr; }
+        return e;
+    }
     const int H = cfg->hidden, I = cfg->inter, L = cfg->layers, nh = cfg->heads;
     const int span = cfg->pos_buckets > 0 ? cfg->pos_buckets : cfg->max_rel_pos;
     const int P = 2 * span;

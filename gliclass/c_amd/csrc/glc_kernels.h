@@ -86,9 +86,10 @@ template <typename F> inline bool glc_raise_lds_limit(F* kernel, int bytes, std:
     return true;
 }
 
-// Head: gather pooled rows -> Gt [B,H] and class-token rows -> Gc [B*C,H], both fp32.
+// Head: gather pooled rows -> Gt [B,H] and class-token rows -> Gc [B*C,H], both fp32.  Pooled row = position 0, or the last
+// attended token (klen[b]-1) when klen is given.
 const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap,
-                                   float* Gt, float* Gc, int B, int Sp, int H, int C);
+                                   float* Gt, float* Gc, int B, int Sp, int H, int C, const int* klen = nullptr);
 // logits[b*C+j] = <Tt[b], Cc[b*C+j]> (* logit_scale when normalised)
 const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* Cc, float* logits, int B, int C, int H,
                                   int normalize, float logit_scale);
@@ -102,6 +103,20 @@ const char* glc_launch_gather_sel(hipStream_t st, int dtype, const void* src, co
 // Head gather from the compact rows: Gt[b] = Xs[b]; Gc[b*C+j] = Xs[B+b*C+j] or 0 when the class token is absent.
 const char* glc_launch_head_gather_sel(hipStream_t st, int dtype, const void* Xs, const int* cls_pos, int c_cap,
                                        float* Gt, float* Gc, int B, int H, int C);
+
+// ---- decoder-style backbone (decoder.hip) ----
+// X[b*Sp + s, :] = table[ids[b,s]] (pad rows use pad_id); kbias = 0 / -1e30 from the mask
+const char* glc_launch_embed_plain(hipStream_t st, int dtype, const int64_t* ids, const int64_t* mask, const void* table, void* X,
+                                   float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id);
+// Y = w * X * rsqrt(mean(X^2) + eps) row-wise
+const char* glc_launch_rmsnorm(hipStream_t st, int dtype, const void* X, void* Y, const float* w, float eps, int M, int H);
+// in-place rotate-half RoPE on the Q and K heads of QKV [M, (nq+2nkv) d]; cs = [Sp][d/2][cos,sin]; Q additionally * qscale
+const char* glc_launch_rope_qk(hipStream_t st, int dtype, void* QKV, const float* cs, int M, int Sp, int nq, int nkv, int d, float qscale);
+// F[m,i] = silu(GU[m,i]) * GU[m,I+i]
+const char* glc_launch_swiglu(hipStream_t st, int dtype, const void* GU, void* F, size_t M, int I);
+// grouped-query attention on the row-major fused QKV (Q pre-scaled by log2e/sqrt(d)); CTX [B*Sp, nq*d]; impl 1 = straightforward
+const char* glc_launch_attention_gqa(hipStream_t st, int dtype, int impl, const void* QKV, const float* kbias, const int* klen, void* CTX,
+                                     int B, int Sp, int nq, int nkv, int d, int causal);
 
 // dtype conversion fp32 -> T (weights upload), n elements
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);

@@ -125,13 +125,17 @@ __global__ __launch_bounds__(256) void scan_rows_kernel(const int64_t* __restric
 // Gt rows [0,B): pooled = hidden[b, 0, :] ("first" pooling); Gc rows b*C + j: class token j (zeros if absent)
 template <typename T>
 __global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
-                                                          float* __restrict__ Gt, float* __restrict__ Gc, int B, int Sp, int H, int C) {
+                                                          float* __restrict__ Gt, float* __restrict__ Gc, int B, int Sp, int H, int C,
+                                                          const int* __restrict__ klen) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * (1 + C)) return;
     const int lane = threadIdx.x & 63;
     long long src = -1;
     float* dst;
-    if (row < B) { src = (long long)row * Sp; dst = Gt + (size_t)row * H; }
+    if (row < B) {                          // pooled row: position 0 ('first'), or the last attended token when klen is given
+        const int last = klen ? (klen[row] > 0 ? klen[row] - 1 : 0) : 0;
+        src = (long long)row * Sp + last; dst = Gt + (size_t)row * H;
+    }
     else {
         const int r = row - B, b = r / C, j = r - b * C;
         const int pos = j < c_cap ? cls_pos[(size_t)b * c_cap + j] : -1;
@@ -264,11 +268,11 @@ const char* glc_launch_scan_rows(hipStream_t st, const int64_t* ids, const int64
 }
 
 const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap, float* Gt, float* Gc,
-                                   int B, int Sp, int H, int C) {
+                                   int B, int Sp, int H, int C, const int* klen) {
     if (B <= 0 || C < 0 || !X || !cls_pos || !Gt || !Gc) return "head_gather: bad args";
     const int rows = B * (1 + C);
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL(head_gather_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, Gt, Gc, B, Sp, H, C);
+        hipLaunchKernelGGL(head_gather_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, Gt, Gc, B, Sp, H, C, klen);
     });
     return nullptr;
 }

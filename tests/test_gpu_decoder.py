@@ -1,0 +1,114 @@
+"""GPU (-m gpu): the decoder-style backbone (BASELINE.json configs[4]: RoPE + grouped-query causal attention + SwiGLU +
+RMSNorm) against the C oracle, which tests/test_oracle.py pins on transformers' Qwen2Model through
+tests/golden/dec_*.npz.  The fixtures themselves also run through test_gpu_parity.py::test_golden_fixtures.
+Tolerances: see test_gpu_parity.py (fp32 is the parity-grade mode; 16-bit modes are asserted at their measured envelope)."""
+import ctypes as C
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_PROB = {"f32": 1e-4, "f16": 1e-2, "bf16": 6e-2}
+
+
+def sig(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_decoder_live_oracle_sweep(dtype, weights_for):
+    """Shapes outside the fixtures: S not a multiple of 64, B = 1, rows without labels, S = 1."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w = weights_for("dec-mini")
+    eng = Engine(cfg, w, dtype=dtype)
+    try:
+        for (B, S, Cn, lpr, seed) in ((5, 33, 3, [3, 0, 1, 2, 3], 11), (1, 129, 1, None, 12), (3, 64, 2, None, 13), (2, 515, 4, [4, 1], 14)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=seed, ragged=True, labels_per_row=lpr)
+            ref = oracle_c.forward(cfg, w, ids, mask)
+            got = eng.forward(ids, mask)
+            assert got.shape == ref.shape and np.isfinite(got).all()
+            assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (B, S)
+        ids = np.array([[cfg.cls_id]], np.int64)
+        assert eng.forward(ids, np.ones_like(ids), c_alloc=0).shape == (1, 0)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("variant", ["bidirectional", "first-pooling", "mha"])
+def test_decoder_config_switches(variant, weights_for):
+    """causal = 0 (the LLM2Vec-style bidirectional wrapping, unpinned upstream), pooling = 'first', and kv_heads = heads
+    are config switches of the same kernels; checked against the oracle in fp32."""
+    import oracle_c
+    from gliclass.c_amd import synth, weights
+    from gliclass.c_amd.config import POOL_FIRST
+    from gliclass.c_amd.engine import Engine
+    base, _ = weights_for("dec-tiny")
+    cfg = {"bidirectional": dataclasses.replace(base, causal=0),
+           "first-pooling": dataclasses.replace(base, pooling=POOL_FIRST, causal=0),
+           "mha": dataclasses.replace(base, kv_heads=base.heads)}[variant]
+    w = weights.make_weights(cfg, 7)
+    eng = Engine(cfg, w, dtype="f32")
+    try:
+        for (B, S, seed) in ((3, 100, 1), (2, 300, 2)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, 3, seed=seed, ragged=True)
+            ref, hid = oracle_c.forward(cfg, w, ids, mask, want_hidden=True)
+            eng.keep_hidden(True)
+            got = eng.forward(ids, mask)
+            eng.keep_hidden(False)
+            assert np.abs(sig(got) - sig(ref)).max() <= 1e-4
+            m = mask.astype(bool)
+            for which in range(cfg.layers + 1):
+                assert np.abs(eng.hidden(which, B, S)[m] - hid[which][m]).max() <= 3e-4, which
+    finally:
+        eng.close()
+
+
+def test_decoder_rows_are_independent(weights_for):
+    """A row's logits do not depend on its batch neighbours or on the padding it is batched with."""
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w = weights_for("dec-tiny")
+    eng = Engine(cfg, w, dtype="f32")
+    try:
+        ids, mask, _ = synth.make_inputs(cfg, 4, 150, 3, seed=5, ragged=True)
+        full = eng.forward(ids, mask)
+        for b in range(4):
+            n = int(mask[b].sum())
+            solo = eng.forward(ids[b:b + 1, :n], mask[b:b + 1, :n])
+            k = solo.shape[1]
+            assert np.abs(solo[0] - full[b, :k]).max() <= 2e-5
+    finally:
+        eng.close()
+
+
+def test_decoder_through_model_h(weights_for):
+    """The drop-in surface (include/model.h) serves a decoder backbone unchanged: create_ort_session on a synthetic
+    decoder model -> prepare_input_tensors -> run_inference (the reference call sequence, /root/reference/main.c:83-99,141-150)."""
+    import os
+    import oracle_c
+    from gliclass.c_amd import _lib, synth
+    cfg, w = weights_for("dec-tiny")
+    m = _lib.model()
+    os.environ["GLICLASS_DTYPE"] = "f32"
+    try:
+        m.initialize_ort_api()
+        sess = m.create_ort_session(m.initialize_ort_environment(), b"synthetic:dec-tiny:42", 8)
+        assert sess
+        ids, mask, _ = synth.make_inputs(cfg, 3, 90, 2, seed=9, ragged=True)
+        i32, m32 = ids.astype(np.int32), mask.astype(np.int32)
+        rows_i = (C.POINTER(C.c_int) * 3)(*[i32[b].ctypes.data_as(C.POINTER(C.c_int)) for b in range(3)])
+        rows_m = (C.POINTER(C.c_int) * 3)(*[m32[b].ctypes.data_as(C.POINTER(C.c_int)) for b in range(3)])
+        tok = _lib.TokenizedInputs(rows_i, rows_i, rows_m, 3, 90)
+        a, b = C.POINTER(_lib.OrtValue)(), C.POINTER(_lib.OrtValue)()
+        assert m.prepare_input_tensors(C.byref(tok), C.byref(a), C.byref(b)) == 0
+        out = m.run_inference(sess, a, b)
+        ref = oracle_c.forward(cfg, w, ids, mask)
+        assert out and list(out.contents.dims[:2]) == [3, ref.shape[1]]
+        got = np.ctypeslib.as_array(C.cast(out.contents.data, C.POINTER(C.c_float)), shape=ref.shape).copy()
+        assert np.abs(sig(got) - sig(ref)).max() <= 1e-4
+    finally:
+        del os.environ["GLICLASS_DTYPE"]

@@ -226,3 +226,237 @@ const char* glc_launch_attention_gqa(hipStream_t st, int dtype, int impl, const 
     });
     return nullptr;
 }
+
+// =====================================================================================================================
+// MFMA path of the decoder attention (16-bit operands).
+//
+// qkv_layout: one pass over the row-major fused projection that applies RoPE (+ the softmax scale on Q) and writes the
+// operands in the fragment-major order the 32x32x16 MFMA consumes (the same idea as glc_layout.h, head_dim D in {64,128}):
+//   Qf : [b*nq + h ][tile32][s < D/16][lane = 32 hh + r][8]   = Q [32 tile + r    ][16 s + 8 hh + j]
+//   Kf : [b*nkv + g][tile32][s < D/16][lane = 32 hh + r][8]   = K [32 tile + pi(r)][16 s + 8 hh + j]      pi = swap(bit2, bit3)
+//   Vt : [b*nkv + g][tile32][dt < D/32][t < 2][lane = 32 hh + r][8] = V^T[32 dt + r][32 tile + 16 t + 8 hh + j]
+// so every wave-level 16-byte-per-lane load of the attention kernel is one contiguous 1 KiB.
+//
+// attn_gqa_mfma: flash-style, one wave = 32 queries of one query head, 4 waves (4 consecutive query tiles) per block, no
+// LDS and no workgroup barrier:  S^T = K Q^T (D/16 MFMA 32x32x16), online softmax in log2 units with the deferred rescale of
+// attention.hip, O^T += V^T P^T (D/16 MFMA, P^T taken straight from the S^T accumulators thanks to the pi row order of K).
+// Causal: key tiles above the diagonal are never visited, the diagonal tile masks key > query per element; padded keys
+// carry the additive -1e30 bias on tiles at / after the first masked key.  Grouped queries: head h reads K/V of group
+// h / (nq/nkv); the grid keeps all query heads of one (batch, group) on one XCD so they share that group's K/V in L2.
+// =====================================================================================================================
+#include "glc_layout.h"
+
+namespace {
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void qkv_layout_kernel(const T* __restrict__ QKV, const float* __restrict__ cs, T* __restrict__ Qf,
+                                                         T* __restrict__ Kf, T* __restrict__ Vt, int Sp, int nq, int nkv, float qscale) {
+    typedef __attribute__((ext_vector_type(8))) T vec8;
+    constexpr int HD2 = D / 2, NS = D / 16;
+    __shared__ T vs[32][D + 8];
+    const int tile = blockIdx.x, head = blockIdx.y, t = threadIdx.x;           // tile over all B*Sp/32 row tiles
+    const int ld = (nq + 2 * nkv) * D;
+    const int m0 = tile * 32, b = m0 / Sp, st = (m0 - b * Sp) >> 5, nt = Sp >> 5;
+    if (head < nq + nkv) {
+        // ---- Q or K head: RoPE on the (i, i + D/2) pairs, 8 consecutive i per thread ----
+        const bool isq = head < nq;
+        for (int idx = t; idx < 32 * (HD2 / 8); idx += 256) {
+            const int r = idx / (HD2 / 8), c8 = idx - r * (HD2 / 8);           // row in tile, chunk of 8 in the first half
+            const int s = (m0 - b * Sp) + r;
+            const T* src = QKV + (size_t)(m0 + r) * ld + (size_t)head * D + c8 * 8;
+            const vec8 a = *reinterpret_cast<const vec8*>(src);
+            const vec8 bq = *reinterpret_cast<const vec8*>(src + HD2);
+            const float* c = cs + ((size_t)s * HD2 + c8 * 8) * 2;
+            const float sc = isq ? qscale : 1.f;
+            vec8 o1, o2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float co = c[2 * j], sn = c[2 * j + 1], x1 = (float)a[j], x2 = (float)bq[j];
+                o1[j] = (T)((x1 * co - x2 * sn) * sc);
+                o2[j] = (T)((x2 * co + x1 * sn) * sc);
+            }
+            const int lr = isq ? r : glc_pi32(r);                              // K rows sit at lane pi(r)
+            T* dst = isq ? Qf + (((size_t)(b * nq + head) * nt + st) * NS) * 512 : Kf + (((size_t)(b * nkv + (head - nq)) * nt + st) * NS) * 512;
+            const int d1 = c8 * 8, d2 = d1 + HD2;
+            *reinterpret_cast<vec8*>(dst + ((size_t)(d1 >> 4) * 64 + 32 * ((d1 >> 3) & 1) + lr) * 8) = o1;
+            *reinterpret_cast<vec8*>(dst + ((size_t)(d2 >> 4) * 64 + 32 * ((d2 >> 3) & 1) + lr) * 8) = o2;
+        }
+    } else {
+        // ---- V head: transpose the 32 x D tile through LDS ----
+        const int g = head - nq - nkv;
+        for (int idx = t; idx < 32 * (D / 8); idx += 256) {
+            const int r = idx / (D / 8), c8 = idx - r * (D / 8);
+            *reinterpret_cast<vec8*>(&vs[r][c8 * 8]) = *reinterpret_cast<const vec8*>(QKV + (size_t)(m0 + r) * ld + (size_t)(nq + nkv + g) * D + c8 * 8);
+        }
+        __syncthreads();
+        T* dst = Vt + ((size_t)(b * nkv + g) * nt + st) * (size_t)(D / 32) * 2 * 512;
+        for (int u = t; u < (D / 32) * 2 * 64; u += 256) {                     // unit = (dt, tt, lane)
+            const int lane = u & 63, tt = (u >> 6) & 1, dt = u >> 7;
+            const int dd = 32 * dt + (lane & 31), k0 = 16 * tt + 8 * (lane >> 5);
+            vec8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = vs[k0 + j][dd];
+            *reinterpret_cast<vec8*>(dst + (size_t)u * 8) = o;
+        }
+    }
+}
+
+constexpr float DEC_RESCALE_THR = 8.0f;   // log2 units (attention.hip)
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restrict__ Qf, const T* __restrict__ Kf, const T* __restrict__ Vt,
+                                                               const float* __restrict__ kbias, const int* __restrict__ klen,
+                                                               const int* __restrict__ kfirst_, T* __restrict__ CTX, int B, int Sp, int nq,
+                                                               int nkv, int causal) {
+    typedef typename Frag<T>::type frag_t;
+    constexpr int NS = D / 16, ND = D / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int nt = Sp >> 5, nqb = (nt + 3) >> 2, grp = nq / nkv;
+    // XCD-aware decode: blocks b and b + 8 share an XCD; give every block of one (batch, kv group) the same id % 8
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int per = grp * nqb;                               // blocks per (batch, group)
+    const int bg = xcd + 8 * (jj / per), rem = jj % per;
+    if (bg >= B * nkv) return;
+    const int b = bg / nkv, g = bg - b * nkv;
+    const int hq = g * grp + rem / nqb;
+    // longest tiles first within a head (causal work grows with the tile index)
+    const int qt = nt - 1 - ((rem % nqb) * 4 + wave);
+    if (qt < 0) return;
+    const int q0 = qt * 32;
+
+    const T* __restrict__ Qp = Qf + (((size_t)(b * nq + hq) * nt + qt) * NS) * 512 + lane * 8;
+    const T* __restrict__ Kp = Kf + ((size_t)(b * nkv + g) * nt * NS) * 512 + lane * 8;
+    const T* __restrict__ Vp = Vt + ((size_t)(b * nkv + g) * nt * ND * 2) * 512 + lane * 8;
+    const float* __restrict__ kb = kbias + (size_t)b * Sp;
+
+    int nkt = (klen[b] + 31) >> 5;
+    nkt = nkt < 1 ? 1 : (nkt > nt ? nt : nkt);
+    if (causal && nkt > qt + 1) nkt = qt + 1;
+    const int kfirst = kfirst_[b];
+    const int foff = 8 * h;
+
+    frag_t qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const frag_t*>(Qp + s * 512);
+    f32x16 o[ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[a][i] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+
+    frag_t kf[NS], nkf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const frag_t*>(Kp + s * 512);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int ktn = kt + 1 < nkt ? kt + 1 : kt;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) nkf[s] = *reinterpret_cast<const frag_t*>(Kp + (size_t)ktn * NS * 512 + s * 512);
+        frag_t vt[ND][2];
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) vt[a][t] = *reinterpret_cast<const frag_t*>(Vp + ((size_t)kt * ND * 2 + a * 2 + t) * 512);
+        // S^T = K Q^T ; reg i <-> key k0 + 16*(i>>3) + 8h + (i&7), column = query c
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mma32(kf[s], qf[s], sacc);
+        float sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
+        const int k0 = kt * 32;
+        if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sv[i] += b0[i]; sv[4 + i] += b1[i]; sv[8 + i] += b2[i]; sv[12 + i] += b3[i]; }
+        }
+        if (causal && kt == qt) {                                           // diagonal tile: key offset > query offset is masked
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ko = 16 * (i >> 3) + foff + (i & 7);
+                if (ko > c) sv[i] = GLC_NEG_BIG;
+            }
+        }
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+        mx = fmaxf(mx, sv[15]);
+        if (__builtin_amdgcn_ballot_w64(mx - m > DEC_RESCALE_THR) != 0ull) {   // deferred rescale (attention.hip)
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[a][i] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
+        l += psum;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            frag_t pfr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) mma32(vt[a][t], pfr, o[a]);        // O^T[dd = 32a + (i&3) + 8(i>>2) + 4h][query c]
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kf[s] = nkf[s];
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    T* out = CTX + ((size_t)b * Sp + q0 + c) * ((size_t)nq * D) + (size_t)hq * D;
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            store4<T>(out + 32 * a + 8 * gq + 4 * h, o[a][4 * gq] * inv, o[a][4 * gq + 1] * inv, o[a][4 * gq + 2] * inv, o[a][4 * gq + 3] * inv);
+}
+
+template <typename T> const char* launch_layout_t(hipStream_t st, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,
+                                                  int nq, int nkv, int d, float qscale) {
+    const dim3 grid(B * Sp / 32, nq + 2 * nkv), block(256);
+    if (d == 128) hipLaunchKernelGGL((qkv_layout_kernel<T, 128>), grid, block, 0, st, (const T*)QKV, cs, (T*)Qf, (T*)Kf, (T*)Vt, Sp, nq, nkv, qscale);
+    else hipLaunchKernelGGL((qkv_layout_kernel<T, 64>), grid, block, 0, st, (const T*)QKV, cs, (T*)Qf, (T*)Kf, (T*)Vt, Sp, nq, nkv, qscale);
+    return nullptr;
+}
+template <typename T> const char* launch_gqa_t(hipStream_t st, const void* Qf, const void* Kf, const void* Vt, const float* kbias, const int* klen,
+                                               const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal) {
+    const int nt = Sp / 32, nqb = (nt + 3) / 4, per = (nq / nkv) * nqb, bg8 = (B * nkv + 7) / 8 * 8;
+    const dim3 grid(per * bg8), block(256);
+    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
+    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
+    return nullptr;
+}
+
+}  // namespace
+
+// RoPE + softmax scale + fragment-major layout of the fused projection (16-bit T).  Sp % 64 == 0, d in {64, 128}.
+const char* glc_launch_qkv_layout(hipStream_t st, int dtype, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,
+                                  int nq, int nkv, int d, float qscale) {
+    if (!QKV || !cs || !Qf || !Kf || !Vt || B <= 0 || Sp <= 0 || Sp % 64 || nq <= 0 || nkv <= 0 || (d != 64 && d != 128)) return "qkv_layout: bad args";
+    if (dtype == GLC_DT_BF16) return launch_layout_t<bf16_t>(st, QKV, cs, Qf, Kf, Vt, B, Sp, nq, nkv, d, qscale);
+    if (dtype == GLC_DT_F16) return launch_layout_t<f16_t>(st, QKV, cs, Qf, Kf, Vt, B, Sp, nq, nkv, d, qscale);
+    return "qkv_layout: 16-bit operands only";
+}
+
+// MFMA grouped-query attention on the fragment-major operands written by glc_launch_qkv_layout.  CTX [B*Sp, nq*d] row-major.
+const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void* Qf, const void* Kf, const void* Vt, const float* kbias,
+                                          const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal) {
+    if (!Qf || !Kf || !Vt || !kbias || !klen || !kfirst || !CTX || B <= 0 || Sp <= 0 || Sp % 64 || nq <= 0 || nkv <= 0 || nq % nkv ||
+        (d != 64 && d != 128))
+        return "attention_gqa_mfma: bad args";
+    if (dtype == GLC_DT_BF16) return launch_gqa_t<bf16_t>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);
+    if (dtype == GLC_DT_F16) return launch_gqa_t<f16_t>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);
+    return "attention_gqa_mfma: 16-bit operands only";
+}

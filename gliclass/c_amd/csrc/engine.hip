@@ -162,6 +162,11 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
         dfree(e, e->QKV); e->QKV = dmalloc(e, (size_t)Mpad * (nqd + 2 * nkvd) * es); if (!e->QKV) return false;
         dfree(e, e->CTX); e->CTX = dmalloc(e, (size_t)Mpad * nqd * es); if (!e->CTX) return false;
+        if (e->dtype != GLC_F32) {          // fragment-major operands of the MFMA attention kernel
+            dfree(e, e->Qh); e->Qh = dmalloc(e, (size_t)Mpad * nqd * es); if (!e->Qh) return false;
+            dfree(e, e->Kh); e->Kh = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Kh) return false;
+            dfree(e, e->Vt); e->Vt = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Vt) return false;
+        }
         dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false;
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
@@ -270,6 +275,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
       KCHK(glc_launch_embed_plain(st, dt, ids, mask, e->emb, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     const float qscale = 1.4426950408889634f / sqrtf((float)d);         // Q2:186 scaling, times log2(e) for the exp2 softmax
+    const bool mfma = dt != GLC_F32 && e->attn_impl != 1;               // 16-bit: flash-style MFMA kernel; fp32 / impl 1: straightforward kernel
     void *X = e->X, *Xn = e->X2;
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = e->dlayers[l];
@@ -277,8 +283,11 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         GemmArgs g;
         g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H;
         { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, g), false);                                           // Q2:206-208
-          KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }                          // Q2:211
-        { Prof p(e, PC_ATTN); KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
+          if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
+          else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
+        { Prof p(e, PC_ATTN);
+          if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal), false);
+          else KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ;
         { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false); }                                   // Q2:233, :291
@@ -824,7 +833,9 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
  * variant is passed through to the kernel; stamps != 0 adds one launch of the s_memtime-instrumented build and prints
  * the per-tile segment cycles.  Returns ms per launch or < 0. */
 float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum) {
-    if (!e || iters <= 0 || e->dtype == GLC_F32 || e->lastB <= 0) { set_err("attn_bench: needs a 16-bit engine and a previous forward"); return -1.f; }
+    if (!e || iters <= 0 || e->dtype == GLC_F32 || e->lastB <= 0 || e->cfg.backbone != GLC_BACKBONE_DEBERTA) {
+        set_err("attn_bench: needs a 16-bit DeBERTa engine and a previous forward"); return -1.f;
+    }
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHK(hipSetDevice(e->device), -1.f);
     const int B = e->lastB, Sp = e->lastSp, H = e->cfg.hidden, nh = e->cfg.heads;

@@ -117,6 +117,11 @@ const char* glc_launch_swiglu(hipStream_t st, int dtype, const void* GU, void* F
 // grouped-query attention on the row-major fused QKV (Q pre-scaled by log2e/sqrt(d)); CTX [B*Sp, nq*d]; impl 1 = straightforward
 const char* glc_launch_attention_gqa(hipStream_t st, int dtype, int impl, const void* QKV, const float* kbias, const int* klen, void* CTX,
                                      int B, int Sp, int nq, int nkv, int d, int causal);
+// 16-bit MFMA path: RoPE + scale + fragment-major Q / K / V^T (layouts in decoder.hip), then the flash-style kernel
+const char* glc_launch_qkv_layout(hipStream_t st, int dtype, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,
+                                  int nq, int nkv, int d, float qscale);
+const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void* Qf, const void* Kf, const void* Vt, const float* kbias,
+                                          const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal);
 
 // dtype conversion fp32 -> T (weights upload), n elements
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);

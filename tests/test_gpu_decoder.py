@@ -17,18 +17,31 @@ def sig(x):
     return 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
-def test_decoder_live_oracle_sweep(dtype, weights_for):
-    """Shapes outside the fixtures: S not a multiple of 64, B = 1, rows without labels, S = 1."""
+_SWEEP = ((5, 33, 3, [3, 0, 1, 2, 3], 11), (1, 129, 1, None, 12), (3, 64, 2, None, 13), (2, 515, 4, [4, 1], 14))
+
+
+@pytest.fixture(scope="module")
+def sweep_refs(weights_for):
+    """Oracle logits of the sweep shapes, computed once for the three operand types."""
     import oracle_c
     from gliclass.c_amd import synth
+    cfg, w = weights_for("dec-mini")
+    out = []
+    for (B, S, Cn, lpr, seed) in _SWEEP:
+        ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=seed, ragged=True, labels_per_row=lpr)
+        out.append((ids, mask, oracle_c.forward(cfg, w, ids, mask)))
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_decoder_live_oracle_sweep(dtype, weights_for, sweep_refs):
+    """Shapes outside the fixtures: S not a multiple of 64, B = 1, rows without labels, S = 1."""
     from gliclass.c_amd.engine import Engine
     cfg, w = weights_for("dec-mini")
     eng = Engine(cfg, w, dtype=dtype)
     try:
-        for (B, S, Cn, lpr, seed) in ((5, 33, 3, [3, 0, 1, 2, 3], 11), (1, 129, 1, None, 12), (3, 64, 2, None, 13), (2, 515, 4, [4, 1], 14)):
-            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=seed, ragged=True, labels_per_row=lpr)
-            ref = oracle_c.forward(cfg, w, ids, mask)
+        for (ids, mask, ref) in sweep_refs:
+            B, S = ids.shape
             got = eng.forward(ids, mask)
             assert got.shape == ref.shape and np.isfinite(got).all()
             assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (B, S)
@@ -63,6 +76,36 @@ def test_decoder_config_switches(variant, weights_for):
             m = mask.astype(bool)
             for which in range(cfg.layers + 1):
                 assert np.abs(eng.hidden(which, B, S)[m] - hid[which][m]).max() <= 3e-4, which
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("causal", [1, 0])
+def test_decoder_mfma_attention_equals_simple_attention(dtype, causal, weights_for):
+    """The flash-style MFMA kernel (fragment-major operands, RoPE applied by the layout pass) and the straightforward kernel
+    (row-major operands, RoPE in place) see the same rounded Q/K/V, so layer outputs agree to accumulation-order noise —
+    including the diagonal (causal) tiles, ragged key lengths and S that is not a multiple of 64."""
+    from gliclass.c_amd import synth, weights
+    from gliclass.c_amd.engine import Engine
+    base, _ = weights_for("dec-mini")
+    cfg = dataclasses.replace(base, causal=causal)
+    w = weights.make_weights(cfg, 42)
+    eng = Engine(cfg, w, dtype=dtype)
+    try:
+        for (B, S, seed) in ((3, 77, 1), (2, 640, 2), (1, 1100, 3)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, 2, seed=seed, ragged=True)
+            outs = []
+            for impl in (1, 2):
+                eng.set_attention_impl(impl)
+                eng.keep_hidden(True)
+                eng.forward(ids, mask)
+                outs.append(eng.hidden(1, B, S))
+            eng.set_attention_impl(0)
+            eng.keep_hidden(False)
+            m = mask.astype(bool)
+            tol = 2e-2 if dtype == "f16" else 1.5e-1
+            assert np.abs(outs[0][m] - outs[1][m]).max() <= tol, (B, S)
     finally:
         eng.close()
 

@@ -38,6 +38,26 @@ class Engine:
         if not self.h:
             raise RuntimeError("glc_engine_create: " + self.L.glc_last_error().decode())
 
+    @classmethod
+    def from_spec(cls, cfg: GLiClassConfig, spec: str, dtype="f16", device=0):
+        """Engine from a model path / "synthetic:<config>[:seed]" through the C weight source (glc_weights_load, the same
+        code create_ort_session uses) — no Python-side copy of the tensors, which matters for the 1.5 B-parameter config."""
+        M = _lib.model()
+        w = _lib.Weights()
+        if M.glc_weights_load(spec.encode(), C.byref(w)) != 0:
+            raise RuntimeError(f"glc_weights_load({spec}) failed")
+        self = cls.__new__(cls)
+        self.L = _lib.hip()
+        self.cfg = cfg
+        self.dtype = dtype
+        try:
+            self.h = self.L.glc_engine_create(C.byref(w.cfg), C.cast(w.tensors, C.POINTER(C.c_void_p)), w.n_tensors, device, DTYPES[dtype])
+        finally:
+            M.glc_weights_free(C.byref(w))
+        if not self.h:
+            raise RuntimeError("glc_engine_create: " + self.L.glc_last_error().decode())
+        return self
+
     def close(self):
         if getattr(self, "h", None):
             self.L.glc_engine_destroy(self.h)

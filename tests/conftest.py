@@ -34,3 +34,27 @@ def weights_for():
             _WCACHE[(name, seed)] = (CONFIGS[name], weights.make_weights(CONFIGS[name], seed))
         return _WCACHE[(name, seed)]
     return get
+
+
+@pytest.fixture
+def c_generated_weights():
+    """(spec, cfg) -> name -> numpy dict of a synthetic model from the C weight source (glc_weights_load, the code
+    create_ort_session uses), WITHOUT copying: the 0.4-1.5 B-parameter configs take minutes through the numpy generator.
+    The mappings are released when the test ends."""
+    import ctypes as C
+    import numpy as np
+    from gliclass.c_amd import _lib
+    from gliclass.c_amd.weights import tensor_specs
+    handles = []
+
+    def get(spec, cfg):
+        M = _lib.model()
+        w = _lib.Weights()
+        assert M.glc_weights_load(spec.encode(), C.byref(w)) == 0
+        handles.append(w)
+        specs = tensor_specs(cfg)
+        assert w.n_tensors == len(specs)
+        return {name: np.ctypeslib.as_array(w.tensors[i], shape=tuple(shape)) for i, (name, shape, _, _) in enumerate(specs)}
+    yield get
+    for w in handles:
+        _lib.model().glc_weights_free(C.byref(w))

@@ -312,3 +312,24 @@ def test_full_size_base_row_vs_oracle(weights_for):
     print("base S=1024 max prob err vs oracle:", res)
     assert res["f32"] <= 1e-4
     assert res["f16"] <= 1e-2          # measured 0.6e-3 ... 2.7e-3 (12 layers)
+
+
+def test_large_config_c4_shape(c_generated_weights):
+    """BASELINE.json configs[3] (gliclass-large shape: 24 layers, H 1024, 16 heads, I 4096) — the per-GPU shard of the 8-GPU run is
+    the same engine at B = 32; here a short ragged batch against the oracle in the parity-grade mode, plus f16 inside its envelope."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    cfg = CONFIGS["large"]
+    w = c_generated_weights("synthetic:large:42", cfg)
+    ids, mask, _ = synth.make_inputs(cfg, 2, 200, 4, seed=41, ragged=True, labels_per_row=[4, 2])
+    ref = oracle_c.forward(cfg, w, ids, mask)
+    for dtype in ("f32", "f16"):
+        eng = Engine.from_spec(cfg, "synthetic:large:42", dtype=dtype)
+        try:
+            got = eng.forward(ids, mask)
+        finally:
+            eng.close()
+        assert got.shape == ref.shape
+        assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], dtype

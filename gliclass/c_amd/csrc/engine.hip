@@ -70,6 +70,7 @@ struct glc_engine {
     std::vector<DecLayerW> dlayers; float* final_norm = nullptr;      // decoder backbone
     std::map<int, float*> ropes;                                      // Sp -> [Sp][d/2][cos,sin]
     void *QKV = nullptr, *GU = nullptr, *X2 = nullptr;                // decoder workspace: fused QKV rows, [gate|up] rows, second residual buffer
+    bool fused_swiglu = false;                                        // Wgu rows interleaved 16 gate / 16 up: SwiGLU runs in the GEMM epilogue
     float* headw[8] = {nullptr};
     int P = 0;
     // workspace
@@ -167,7 +168,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
             dfree(e, e->Kh); e->Kh = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Kh) return false;
             dfree(e, e->Vt); e->Vt = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Vt) return false;
         }
-        dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false;
+        if (!e->fused_swiglu) { dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
         e->capM = Mpad;
@@ -295,8 +296,9 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
-        { Prof p(e, PC_FFN1); KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, f1), false);                                         // Q2:47 gate | up
-          KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); }
+        { Prof p(e, PC_FFN1);                                                                                                  // Q2:47 silu(gate) * up
+          if (e->fused_swiglu) { f1.C = e->FF; KCHK(glc_launch_gemm256s(st, dt, EPI_SWIGLU, f1), false); }
+          else { KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); } }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I;
         { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false); }
@@ -447,6 +449,7 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
     size_t stage_n = (size_t)c.vocab * H;
     if ((size_t)I * H > stage_n) stage_n = (size_t)I * H;
     if (NQ * H > stage_n) stage_n = NQ * H;
+    if (2 * (size_t)I * H > stage_n) stage_n = 2 * (size_t)I * H;
     float* staging = nullptr;
     if (hipMalloc((void**)&staging, stage_n * sizeof(float)) != hipSuccess) { set_err("staging alloc failed"); return false; }
     bool ok = false;
@@ -454,7 +457,10 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
         e->emb = dmalloc(e, (size_t)c.vocab * H * es, false);
         if (!e->emb || !upload_as(e, tensors[0], (size_t)c.vocab * H, e->emb, staging)) break;
         e->dlayers.resize(L);
-        std::vector<float> bqkv(NQKV);
+        // SwiGLU in the epilogue of the staggered 256-tile GEMM when the shapes allow it (16-bit operands)
+        e->fused_swiglu = e->dtype != GLC_F32 && (2 * I) % 256 == 0 && H % 32 == 0 && I % 16 == 0 && glc_gemm_use_stagger() &&
+                          getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
+        std::vector<float> bqkv(NQKV), gu_host(e->fused_swiglu ? 2 * (size_t)I * H : 0);
         bool lok = true;
         for (int l = 0; l < L && lok; ++l) {
             const float* const* t = tensors + 1 + GLC_DEC_TENSORS_PER_LAYER * l;    // ln1 qw qb kw kb vw vb ow ln2 gw uw dw
@@ -466,8 +472,17 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
             if (!w.Wqkv || !w.Wo || !w.Wgu || !w.Wd) { lok = false; break; }
             lok = upload_as(e, t[1], NQ * H, w.Wqkv, staging) && upload_as(e, t[3], NKV * H, (char*)w.Wqkv + NQ * H * es, staging) &&
                   upload_as(e, t[5], NKV * H, (char*)w.Wqkv + (NQ + NKV) * H * es, staging) && upload_as(e, t[7], (size_t)H * NQ, w.Wo, staging) &&
-                  upload_as(e, t[9], (size_t)I * H, w.Wgu, staging) && upload_as(e, t[10], (size_t)I * H, (char*)w.Wgu + (size_t)I * H * es, staging) &&
                   upload_as(e, t[11], (size_t)H * I, w.Wd, staging);
+            if (lok && e->fused_swiglu) {
+                // rows [32 f, 32 f + 16) = gate rows of features 16 f .. 16 f + 15, rows [32 f + 16, 32 f + 32) = their up rows
+                for (int f = 0; f < I / 16; ++f) {
+                    memcpy(gu_host.data() + (size_t)(32 * f) * H, t[9] + (size_t)(16 * f) * H, (size_t)16 * H * sizeof(float));
+                    memcpy(gu_host.data() + (size_t)(32 * f + 16) * H, t[10] + (size_t)(16 * f) * H, (size_t)16 * H * sizeof(float));
+                }
+                lok = upload_as(e, gu_host.data(), 2 * (size_t)I * H, w.Wgu, staging);
+            } else if (lok) {
+                lok = upload_as(e, t[9], (size_t)I * H, w.Wgu, staging) && upload_as(e, t[10], (size_t)I * H, (char*)w.Wgu + (size_t)I * H * es, staging);
+            }
             if (!lok) break;
             for (size_t i = 0; i < NQ; ++i) bqkv[i] = t[2][i];
             for (size_t i = 0; i < NKV; ++i) { bqkv[NQ + i] = t[4][i]; bqkv[NQ + NKV + i] = t[6][i]; }

@@ -157,7 +157,42 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     const float* __restrict__ bias = p.bias;
     float* stg = reinterpret_cast<float*>(smem256 + wave * EPI_PATCH);
     const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;
-    if (!vmode) {
+    if constexpr (EPI == EPI_SWIGLU) {
+        // W rows alternate 16 gate features / 16 up features (engine.hip interleaves them at load), so the accumulator
+        // blocks j = 0,2 hold gate and j = 1,3 the matching up columns of the SAME 16 features: the product needs no
+        // exchange.  The wave's 128x64 sub-tile becomes 128x32 outputs (Q2:47 silu(gate(x)) * up(x)); patch [32 rows][32
+        // features], row stride 36 floats; 16-byte stores of 8 features.
+        const int I = N >> 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const f32x4 gt = acc[2 * c + ii][2 * jj], up = acc[2 * c + ii][2 * jj + 1];
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = gt[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt[r])) * up[r];
+                    *reinterpret_cast<f32x4*>(stg + (ii * 16 + r16) * 36 + jj * 16 + 4 * g) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 2, g4 = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 36 + g4 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 36 + g4 * 8 + 4);
+                vec8T o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (T)lo[e]; o[4 + e] = (T)hi[e]; }
+                const int m = m0 + wm * 128 + c * 32 + row;
+                *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * I + (n0 >> 1) + wn * 32 + g4 * 8) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (!vmode) {
         // D[n = 16j + 4g + r][m = 16i + r16]; patch [32 rows m][64 cols n], row stride 68 floats
         const int which = (EPI == EPI_QKV) ? n0 / p.H : 0;
         float bj[4][4];
@@ -284,6 +319,7 @@ template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmAr
         case EPI_BIAS: return launch_e<T, EPI_BIAS, false>(st, a, 0, ntn);
         case EPI_GELU: return launch_e<T, EPI_GELU, false>(st, a, 0, ntn);
         case EPI_RESID: return launch_e<T, EPI_RESID, false>(st, a, 0, ntn);
+        case EPI_SWIGLU: return launch_e<T, EPI_SWIGLU, false>(st, a, 0, ntn);
         case EPI_QKV: {   // Q|K columns in row orientation, V columns transposed: two grids, one stream
             const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;     // skip the Q columns when asked
             const char* m = launch_e<T, EPI_QKV, false>(st, a, nq, nqk - nq);
@@ -310,6 +346,7 @@ const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmAr
         if (a.H % 256 || a.N != 3 * a.H || a.Sp % 64 || a.Sp < 64 || !a.Qh || !a.Kh || !a.Vt || a.nh * 64 != a.H) return "gemm256s: bad QKV epilogue shape";
     } else if (!a.C) return "gemm256s: null output";
     if (epi == EPI_RESID && !a.resid) return "gemm256s: null residual";
+    if (epi == EPI_SWIGLU && a.bias) return "gemm256s: the SwiGLU epilogue takes no bias";
     return dtype == GLC_DT_BF16 ? launch_t<bf16_t>(st, epi, a) : launch_t<f16_t>(st, epi, a);
 }
 

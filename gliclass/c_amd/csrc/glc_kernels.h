@@ -6,7 +6,8 @@
 #include <stdint.h>
 
 enum { GLC_DT_F32 = 0, GLC_DT_BF16 = 1, GLC_DT_F16 = 2 };  // == GLC_F32/BF16/F16 of gliclass_hip.h
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3,
+       EPI_SWIGLU = 4 };   // gemm256s only: W rows interleave 16 gate / 16 up features; C [Mpad, N/2] = silu(gate) * up
 
 struct GemmArgs {
     const void* A = nullptr;      // [Mpad, K]  T

@@ -312,6 +312,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         Prof p(e, PC_HEAD);
         float* Gc = e->Gt + (size_t)round_up(B, 128) * H;
         KCHK(glc_launch_head_gather(st, dt, e->H1, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C, c.pooling == GLC_POOL_LAST ? e->klen : nullptr), false);
+        if (c.pooling == GLC_POOL_AVG) KCHK(glc_launch_pool_avg(st, dt, e->H1, e->kbias, e->Gt, B, Sp, H), false);
         const int rt = round_up(B, 128), rc = round_up(B * C, 128);
         GemmArgs h;
         h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
@@ -420,7 +421,10 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         Prof p(e, PC_HEAD);
         float* Gc = e->Gt + (size_t)round_up(B, 128) * H;
         if (prune) KCHK(glc_launch_head_gather_sel(st, dt, e->Xs, e->cls_pos, ccap, e->Gt, Gc, B, H, C), false);
-        else KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C), false);
+        else {
+            KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C, c.pooling == GLC_POOL_LAST ? e->klen : nullptr), false);
+            if (c.pooling == GLC_POOL_AVG) KCHK(glc_launch_pool_avg(st, dt, e->X, e->kbias, e->Gt, B, Sp, H), false);
+        }
         // text rows [0, rt) and class rows [rt, rt + rc) share one fp32 buffer; one two-group GEMM per projector stage
         const int rt = round_up(B, 128), rc = round_up(B * C, 128);
         GemmArgs h;
@@ -556,8 +560,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         set_err("engine_create: decoder backbone needs head_dim 64 or 128, heads % kv_heads == 0 and rope_theta > 1"); return nullptr;
     }
     if (cfg->hidden % 128 || cfg->inter % 128) { set_err("engine_create: hidden and intermediate sizes must be multiples of 128"); return nullptr; }
-    if ((cfg->pooling != GLC_POOL_FIRST && !(dec && cfg->pooling == GLC_POOL_LAST)) || cfg->scorer != GLC_SCORER_DOT) {
-        set_err("engine_create: only pooling='first' (and 'last' on decoder backbones) with scorer='simple' are implemented"); return nullptr;
+    if (cfg->pooling < GLC_POOL_FIRST || cfg->pooling > GLC_POOL_LAST || cfg->scorer != GLC_SCORER_DOT) {
+        set_err("engine_create: pooling must be 'first', 'avg' or 'last' and the scorer 'simple' (other upstream scorers are not implemented)"); return nullptr;
     }
     int ndev = glc_device_count();
     if (ndev <= 0) { set_err("engine_create: no HIP device visible (this engine has no CPU path)"); return nullptr; }

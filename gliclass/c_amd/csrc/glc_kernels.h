@@ -91,6 +91,8 @@ template <typename F> inline bool glc_raise_lds_limit(F* kernel, int bytes, std:
 // attended token (klen[b]-1) when klen is given.
 const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, const int* cls_pos, int c_cap,
                                    float* Gt, float* Gc, int B, int Sp, int H, int C, const int* klen = nullptr);
+// pooling = 'avg': Gt[b,:] = mean over the attended positions (kbias == 0) of X[b,s,:]
+const char* glc_launch_pool_avg(hipStream_t st, int dtype, const void* X, const float* kbias, float* Gt, int B, int Sp, int H);
 // logits[b*C+j] = <Tt[b], Cc[b*C+j]> (* logit_scale when normalised)
 const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* Cc, float* logits, int B, int C, int H,
                                   int normalize, float logit_scale);

@@ -145,6 +145,27 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const T* __restrict__ 
     for (int i = lane; i < H; i += 64) dst[i] = src >= 0 ? (float)X[(size_t)src * H + i] : 0.f;
 }
 
+// pooling = 'avg': Gt[b, :] = mean of X[b, s, :] over the attended positions (kbias == 0); block = (64 columns, batch row)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_avg_kernel(const T* __restrict__ X, const float* __restrict__ kbias, float* __restrict__ Gt,
+                                                       int Sp, int H) {
+    __shared__ float red[4][64];
+    __shared__ int cnt[4];
+    const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float acc = 0.f;
+    int n = 0;
+    for (int s = ph; s < Sp; s += 4)
+        if (kbias[(size_t)b * Sp + s] == 0.f) { acc += (float)X[((size_t)b * Sp + s) * H + col]; ++n; }
+    red[ph][threadIdx.x & 63] = acc;
+    if ((threadIdx.x & 63) == 0) cnt[ph] = n;
+    __syncthreads();
+    if (ph == 0) {
+        const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        Gt[(size_t)b * H + col] = tot > 0 ? v / (float)tot : 0.f;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
                                                           T* __restrict__ Xs, int* __restrict__ sel_b, int* __restrict__ sel_q,
@@ -274,6 +295,12 @@ const char* glc_launch_head_gather(hipStream_t st, int dtype, const void* X, con
     DISPATCH_T(dtype, {
         hipLaunchKernelGGL(head_gather_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)X, cls_pos, c_cap, Gt, Gc, B, Sp, H, C, klen);
     });
+    return nullptr;
+}
+
+const char* glc_launch_pool_avg(hipStream_t st, int dtype, const void* X, const float* kbias, float* Gt, int B, int Sp, int H) {
+    if (B <= 0 || Sp <= 0 || H % 64 || !X || !kbias || !Gt) return "pool_avg: bad args";
+    DISPATCH_T(dtype, { hipLaunchKernelGGL(pool_avg_kernel<T>, dim3(H / 64, B), dim3(256), 0, st, (const T*)X, kbias, Gt, Sp, H); });
     return nullptr;
 }
 

@@ -152,10 +152,14 @@ static void glo_head(const glo_config* cfg, const float* const* hw, const float*
             int last = 0;
             for (int s = 0; s < S; ++s) if (mask[(size_t)b * S + s]) last = s;
             memcpy(pooled, X + ((size_t)b * S + last) * H, (size_t)H * sizeof(float));
-        } else {
-            for (int s = 0; s < S; ++s)
+        } else {                                /* 'avg': mean over the attended positions */
+            int n = 0;
+            for (int s = 0; s < S; ++s) {
+                if (!mask[(size_t)b * S + s]) continue;
+                ++n;
                 for (int i = 0; i < H; ++i) pooled[i] += X[((size_t)b * S + s) * H + i];
-            for (int i = 0; i < H; ++i) pooled[i] /= (float)S;
+            }
+            for (int i = 0; i < H; ++i) pooled[i] = n ? pooled[i] / (float)n : 0.f;
         }
         int j = 0;
         for (int s = 0; s < S && j < C; ++s)

@@ -87,8 +87,9 @@ def gliclass_head(cfg: GLiClassConfig, tensors, hidden, ids, mask):
         classes[b, :len(pos)] = hidden[b, pos]
     if cfg.pooling == POOL_FIRST:
         pooled = hidden[:, 0, :]
-    elif cfg.pooling == POOL_AVG:
-        pooled = hidden.mean(1)
+    elif cfg.pooling == POOL_AVG:           # mean over the attended positions
+        mk = mask.to(hidden.dtype).unsqueeze(-1)
+        pooled = (hidden * mk).sum(1) / mk.sum(1).clamp(min=1)
     elif cfg.pooling == POOL_LAST:
         last = torch.stack([torch.nonzero(mask[b]).flatten()[-1] if mask[b].any() else torch.tensor(0) for b in range(B)])
         pooled = hidden[torch.arange(B), last]

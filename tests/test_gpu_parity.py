@@ -333,3 +333,27 @@ def test_large_config_c4_shape(c_generated_weights):
             eng.close()
         assert got.shape == ref.shape
         assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], dtype
+
+
+@pytest.mark.parametrize("pooling", ["avg", "last"])
+def test_pooling_switches(pooling, weights_for):
+    """pooling = 'avg' (mean over the attended positions) and 'last' are config switches of the head (SURVEY.md §8a row a12:
+    "must be config-switchable"; upstream semantics unpinned); checked against the oracle in fp32 and f16.  These switches
+    disable the last-layer pruning (it assumes the pooled row is position 0)."""
+    import dataclasses
+    import oracle_c
+    from gliclass.c_amd import synth, weights
+    from gliclass.c_amd.config import POOL_AVG, POOL_LAST
+    from gliclass.c_amd.engine import Engine
+    base, _ = weights_for("tiny")
+    cfg = dataclasses.replace(base, pooling={"avg": POOL_AVG, "last": POOL_LAST}[pooling])
+    w = weights.make_weights(cfg, 42)
+    ids, mask, _ = synth.make_inputs(cfg, 4, 150, 3, seed=17, ragged=True, labels_per_row=[3, 1, 0, 2])
+    ref = oracle_c.forward(cfg, w, ids, mask)
+    for dtype in ("f32", "f16"):
+        eng = Engine(cfg, w, dtype=dtype)
+        try:
+            got = eng.forward(ids, mask)
+        finally:
+            eng.close()
+        assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], dtype

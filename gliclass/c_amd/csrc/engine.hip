@@ -11,6 +11,7 @@
 
 #include <map>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,8 @@ struct glc_engine {
     glc_model_config cfg{};
     int dtype = GLC_F32, device = 0, attn_impl = 0;
     bool prune_last = true;         // last layer only on the rows the head reads (exact)
+    int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
+    int last_groups = 1;            // groups the last host-buffer forward ran as
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::vector<void*> allocs;      // everything freed at destroy
@@ -572,6 +575,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     e->cfg = *cfg; e->dtype = dtype; e->device = device;
     if (e->cfg.kv_heads <= 0) e->cfg.kv_heads = e->cfg.heads;
     if (const char* pv = getenv("GLICLASS_PRUNE_LAST")) e->prune_last = atoi(pv) != 0;
+    if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
         if (!create_decoder(e, tensors)) { glc_engine_destroy(e); return nullptr; }
         return e;
@@ -671,24 +675,139 @@ void glc_engine_destroy(glc_engine* e) {
     delete e;
 }
 
-int glc_engine_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, float* logits, int c_alloc, int* c_out) {
-    if (!e || !ids || !mask || (!logits && c_alloc > 0)) { set_err("forward: null argument"); return -1; }
-    if (!check_shape(e, B, S, c_alloc)) return -1;
-    std::lock_guard<std::mutex> lk(e->mu);
-    HIPCHK(hipSetDevice(e->device), -1);
+// One padded batch: H2D, launch sequence, D2H of logits [B, c_alloc] and per-row class-token counts.  Caller holds e->mu.
+static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, float* logits, int c_alloc, int* cnt) {
     if (!ensure_capacity(e, B, S, c_alloc)) return -1;
     const size_t nb = (size_t)B * S * sizeof(int64_t);
     HIPCHK(hipMemcpyAsync(e->d_ids, ids, nb, hipMemcpyHostToDevice, e->stream), -1);
     HIPCHK(hipMemcpyAsync(e->d_mask, mask, nb, hipMemcpyHostToDevice, e->stream), -1);
     if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) return -1;
-    std::vector<int> cnt(B);
-    HIPCHK(hipMemcpyAsync(cnt.data(), e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
+    HIPCHK(hipMemcpyAsync(cnt, e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
     if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
     HIPCHK(hipStreamSynchronize(e->stream), -1);
     if (e->profile) prof_collect(e);
+    return 0;
+}
+
+// Length bucketing: the reference pads every row of a batch to the longest one
+// (/root/reference/src/tokenizer.c:44-54).  Rows are independent end to end and columns past a row's last attended token
+// contribute nothing, so a ragged batch can run as a few groups of similar length, each padded only to ITS longest row.
+// Plans the partition of the rows (sorted by length) into <= max_groups contiguous groups that minimises
+// sum_g ( BucketCost(n_g * roundup(len_g, 64)) + kBucketOverheadRows ); returns the group boundaries in `cuts`
+// (indices into `order`).  A coarse cost model in units of padded token rows: the 256-row GEMM tiles of the narrowest
+// projection (N = hidden) fill the chip in whole waves of `quantum` = 256 * CUs / (hidden / 256) rows — measured: config c3's
+// 65 536 rows are exactly three waves, and two forwards of 32 768 rows each take LONGER than one of 65 536 — and every
+// extra forward costs about 1 k rows of fixed work (head, pruned last layer, launch sequence).
+constexpr int kBucketOverheadRows = 1024;
+// cost of a forward of `rows` padded token rows, in row units: its 256-row tiles of the N = hidden projections run in whole
+// waves over the CUs (256 CUs assumed when no device is visible)
+struct BucketCost {
+    int ncu = 256, nt = 1;
+    explicit BucketCost(int hidden) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+        nt = hidden / 256 > 0 ? hidden / 256 : 1;
+    }
+    long long operator()(long long rows) const {
+        const long long blocks = (rows + 255) / 256 * nt, waves = (blocks + ncu - 1) / ncu;
+        return waves * 256 * ncu / nt;
+    }
+};
+
+static void plan_buckets(const std::vector<int>& len, int max_groups, const BucketCost& cost, std::vector<int>& order, std::vector<int>& cuts) {
+    const int B = (int)len.size();
+    order.resize(B);
+    for (int i = 0; i < B; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });     // longest first
+    auto sp = [&](int i) { return round_up(len[order[i]] > 0 ? len[order[i]] : 1, 64); };
+    const int G = max_groups < 1 ? 1 : (max_groups > B ? B : max_groups);
+    // best[g][i]: minimal cost of covering rows [i, B) with exactly g groups; a group [i, j) costs (j - i) * sp(i)
+    const long long INF = 1ll << 60;
+    std::vector<std::vector<long long>> best(G + 1, std::vector<long long>(B + 1, INF));
+    std::vector<std::vector<int>> nxt(G + 1, std::vector<int>(B + 1, B));
+    for (int g = 0; g <= G; ++g) best[g][B] = g == 0 ? 0 : INF;
+    for (int g = 1; g <= G; ++g)
+        for (int i = B - 1; i >= 0; --i)
+            for (int j = i + 1; j <= B; ++j) {
+                if (best[g - 1][j] >= INF) continue;
+                const long long rows = (long long)(j - i) * sp(i);
+                const long long c = cost(rows) + kBucketOverheadRows + best[g - 1][j];
+                if (c < best[g][i]) { best[g][i] = c; nxt[g][i] = j; }
+            }
+    int gbest = 1;
+    for (int g = 2; g <= G; ++g) if (best[g][0] < best[gbest][0]) gbest = g;
+    cuts.clear();
+    for (int g = gbest, i = 0; g >= 1 && i < B; --g) { cuts.push_back(i); i = nxt[g][i]; }
+    cuts.push_back(B);
+}
+
+int glc_engine_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, float* logits, int c_alloc, int* c_out) {
+    if (!e || !ids || !mask || (!logits && c_alloc > 0)) { set_err("forward: null argument"); return -1; }
+    if (!check_shape(e, B, S, c_alloc)) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1);
+    std::vector<int> cnt(B);
+    std::vector<int> order, cuts;
+    if (e->max_buckets > 1 && B > 1 && !e->keep_hidden) {
+        // a row's effective length: one past its last attended token or class token
+        std::vector<int> len(B, 0);
+        for (int b = 0; b < B; ++b) {
+            const int64_t* mk = mask + (size_t)b * S;
+            const int64_t* id = ids + (size_t)b * S;
+            int l = 0;
+            for (int s = S - 1; s >= 0; --s) if (mk[s] != 0 || id[s] == e->cfg.class_token_index) { l = s + 1; break; }
+            len[b] = l;
+        }
+        plan_buckets(len, e->max_buckets, BucketCost(e->cfg.hidden), order, cuts);
+        if (cuts.size() > 2) {
+            std::vector<int64_t> gi, gm;
+            std::vector<float> gl;
+            for (size_t g = 0; g + 1 < cuts.size(); ++g) {
+                const int i0 = cuts[g], n = cuts[g + 1] - cuts[g];
+                int Sg = len[order[i0]];
+                Sg = Sg < 1 ? 1 : Sg;
+                gi.assign((size_t)n * Sg, 0); gm.assign((size_t)n * Sg, 0); gl.assign((size_t)n * (c_alloc > 0 ? c_alloc : 1), 0.f);
+                for (int r = 0; r < n; ++r) {
+                    memcpy(gi.data() + (size_t)r * Sg, ids + (size_t)order[i0 + r] * S, (size_t)Sg * sizeof(int64_t));
+                    memcpy(gm.data() + (size_t)r * Sg, mask + (size_t)order[i0 + r] * S, (size_t)Sg * sizeof(int64_t));
+                }
+                std::vector<int> gc(n);
+                if (forward_one(e, gi.data(), gm.data(), n, Sg, gl.data(), c_alloc, gc.data()) != 0) return -1;
+                for (int r = 0; r < n; ++r) {
+                    cnt[order[i0 + r]] = gc[r];
+                    if (c_alloc > 0) memcpy(logits + (size_t)order[i0 + r] * c_alloc, gl.data() + (size_t)r * c_alloc, (size_t)c_alloc * sizeof(float));
+                }
+            }
+            int cmax = 0;
+            for (int b = 0; b < B; ++b) cmax = cnt[b] > cmax ? cnt[b] : cmax;
+            if (c_out) *c_out = cmax;
+            e->last_groups = (int)cuts.size() - 1;
+            return 0;
+        }
+    }
+    e->last_groups = 1;
+    if (forward_one(e, ids, mask, B, S, logits, c_alloc, cnt.data()) != 0) return -1;
     int cmax = 0;
     for (int b = 0; b < B; ++b) cmax = cnt[b] > cmax ? cnt[b] : cmax;
     if (c_out) *c_out = cmax;
+    return 0;
+}
+
+int glc_plan_length_buckets(const int* lengths, int B, int max_groups, int hidden, int* order, int* cuts, int* n_groups) {
+    if (!lengths || B <= 0 || hidden <= 0 || !order || !cuts || !n_groups) { set_err("plan_length_buckets: bad args"); return -1; }
+    std::vector<int> len(lengths, lengths + B), ord, cu;
+    plan_buckets(len, max_groups, BucketCost(hidden), ord, cu);
+    for (int i = 0; i < B; ++i) order[i] = ord[i];
+    for (size_t i = 0; i < cu.size(); ++i) cuts[i] = cu[i];
+    *n_groups = (int)cu.size() - 1;
+    return 0;
+}
+
+int glc_debug_last_forward_groups(const glc_engine* e) { return e ? e->last_groups : -1; }
+
+int glc_engine_set_length_buckets(glc_engine* e, int max_groups) {
+    if (!e || max_groups < 1 || max_groups > 64) { set_err("set_length_buckets: 1..64 groups"); return -1; }
+    e->max_buckets = max_groups;
     return 0;
 }
 

@@ -91,6 +91,10 @@ class Engine:
     def set_prune_last_layer(self, on=True):
         self.L.glc_engine_set_prune_last_layer(self.h, int(on))
 
+    def set_length_buckets(self, max_groups):
+        if self.L.glc_engine_set_length_buckets(self.h, int(max_groups)) != 0:
+            raise self._err("glc_engine_set_length_buckets")
+
     def keep_hidden(self, on=True):
         self.L.glc_debug_keep_hidden(self.h, int(on))
 

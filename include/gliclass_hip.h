@@ -95,6 +95,17 @@ int glc_engine_sync(glc_engine* e);
  * Q / attention output / FFN only for the rows the head reads ([CLS] + class tokens).  Logits are unchanged. */
 int glc_engine_set_prune_last_layer(glc_engine* e, int on);
 
+/* Length bucketing of glc_engine_forward (host buffers): the reference pads every row of a batch to the longest one
+ * (/root/reference/src/tokenizer.c:44-54); rows are independent, so a ragged batch is run as up to `max_groups` groups of
+ * similar length, each padded to its own longest row (results per row are unchanged; only padding work is saved).
+ * Default 4 (env GLICLASS_LENGTH_BUCKETS), 1 = off.  The device-resident forward is never bucketed. */
+int glc_engine_set_length_buckets(glc_engine* e, int max_groups);
+/* The planner on its own (host only, no GPU): rows sorted longest first into `order` [B]; group g = order[cuts[g] .. cuts[g+1]);
+ * cuts has *n_groups + 1 entries (caller provides B + 1).  Cost model (engine.hip): padded token rows rounded up to whole waves of
+ * 256-row GEMM tiles over the CUs for the N = hidden projections, plus 1024 rows per group. */
+int glc_plan_length_buckets(const int* lengths, int B, int max_groups, int hidden, int* order, int* cuts, int* n_groups);
+int glc_debug_last_forward_groups(const glc_engine* e);   /* how many length groups the last glc_engine_forward ran as */
+
 /* Device memory helpers so a host language can stage buffers without linking HIP itself. */
 void* glc_device_malloc(glc_engine* e, size_t bytes);
 void glc_device_free(glc_engine* e, void* p);

@@ -357,3 +357,34 @@ def test_pooling_switches(pooling, weights_for):
         finally:
             eng.close()
         assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], dtype
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_length_bucketing_preserves_results(dtype, engines, weights_for):
+    """glc_engine_forward splits a ragged batch into length groups (default 4); every row's logits must equal the single padded
+    batch (rows are independent; columns past the last attended token contribute nothing).  Includes a row without labels and
+    a full-length row."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for("small")                      # hidden 768: a wave of 256-row tiles is 21 845 rows, so this batch is 6 waves
+    eng = engines("small", dtype)
+    B, S = 256, 512
+    ids, mask, _ = synth.make_inputs(cfg, B, S, 3, seed=77, ragged=True, labels_per_row=[3, 0, 1, 2] * 64)
+    mask[0, :] = 1                                     # one full-length row
+    lens = mask.sum(1)
+    assert lens.min() < 0.6 * S                        # really ragged
+    eng.set_length_buckets(1)
+    one = eng.forward(ids, mask)
+    assert eng.L.glc_debug_last_forward_groups(eng.h) == 1
+    eng.set_length_buckets(4)
+    got = eng.forward(ids, mask)
+    assert eng.L.glc_debug_last_forward_groups(eng.h) >= 2          # the plan really split this batch
+    assert got.shape == one.shape and eng.last_c == 3
+    tol = 1e-5 if dtype == "f32" else 5e-3             # 16-bit: a different padded length moves tile boundaries (rounding only)
+    assert np.abs(sig(got) - sig(one)).max() <= tol
+    if dtype == "f32":                                 # and against the oracle on a few rows (trimmed: rows are independent)
+        for b in (0, 2, 19):                          # rows with 3, 1 and 2 labels
+            n = int(mask[b].sum())
+            ref = oracle_c.forward(cfg, w, ids[b:b + 1, :n], mask[b:b + 1, :n])
+            k = ref.shape[1]
+            assert np.abs(sig(got[b, :k]) - sig(ref[0])).max() <= TOL_PROB["f32"]

@@ -266,3 +266,39 @@ def test_pure_c_driver_builds_against_the_headers(libs, tmp_path):
         assert r.returncode != 0 and "no MI355X/HIP device" in r.stderr         # loud failure, no CPU path
     else:
         assert r.returncode == 0 and "Text_0" in r.stdout
+
+
+def test_length_bucket_planner():
+    """glc_plan_length_buckets (host only): groups are contiguous in the length-sorted order and cover every row once; the
+    wave-quantised cost model keeps a 64-row batch of the base model in one piece (measured: splitting it is slower), splits a
+    node-sized batch, and never splits equal lengths or reference-sized batches."""
+    import ctypes as C
+    import numpy as np
+    from gliclass.c_amd import _lib
+    L = _lib.hip()
+
+    def plan(lengths, g, hidden=768):
+        B = len(lengths)
+        arr = (C.c_int * B)(*lengths)
+        order, cuts, n = (C.c_int * B)(), (C.c_int * (B + 1))(), C.c_int(0)
+        assert L.glc_plan_length_buckets(arr, B, g, hidden, order, cuts, C.byref(n)) == 0
+        return list(order), list(cuts[: n.value + 1])
+
+    def cost(lengths, order, cuts):
+        rup = lambda x: (max(x, 1) + 63) // 64 * 64
+        waves = lambda rows: -(-(-(-rows // 256) * 3) // 256)               # base model on 256 CUs: 3 tiles per 256 rows at N = 768
+        return sum(waves((cuts[i + 1] - cuts[i]) * rup(lengths[order[cuts[i]]])) * 256 * 256 // 3 + 1024 for i in range(len(cuts) - 1))
+
+    rng = np.random.default_rng(3)
+    lengths = [int(x) for x in rng.integers(512, 1025, size=64)]
+    order, cuts = plan(lengths, 4)
+    assert sorted(order) == list(range(64)) and cuts[0] == 0 and cuts[-1] == 64 and cuts == sorted(cuts)
+    assert all(lengths[order[i]] >= lengths[order[i + 1]] for i in range(63))
+    assert len(cuts) == 2                                                             # c3-sized ragged batch: one piece
+    big = [int(x) for x in rng.integers(512, 1025, size=256)]                          # a node-sized batch pays for groups
+    ob, cb = plan(big, 4)
+    assert 2 <= len(cb) - 1 <= 4 and cost(big, ob, cb) < 0.95 * cost(big, ob, [0, 256])
+    assert cost(big, ob, cb) <= min(cost(big, ob, [0, j, 256]) for j in range(1, 256))  # at least as good as the best 2-split
+    assert len(plan([1024, 900, 800, 700, 650, 600, 550, 520], 4)[1]) == 2
+    assert len(plan([777] * 40, 4)[1]) == 2
+    assert len(plan(big, 1)[1]) == 2

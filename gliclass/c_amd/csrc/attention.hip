@@ -75,6 +75,17 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     if (bh >= a.B * a.nh || q0 >= Sp) return;  // whole wave leaves; no workgroup barriers below
     const int b = bh / a.nh, hh = bh - b * a.nh;
     if (a.tile_flag && !a.tile_flag[(size_t)b * (Sp >> 5) + (q0 >> 5)]) return;   // pruned last layer: no selected row in this query tile
+    if (q0 >= a.klen[b] && q0 > 0) {
+        // every query of this tile lies past the row's last attended token: a padding-only tile of a ragged batch.  Its
+        // output never reaches an attended row (those keys are masked), so skip the work and store zeros (finite).
+        T* outz = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + c) * a.H + hh * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            store4<T>(outz + 8 * g + 4 * h, 0.f, 0.f, 0.f, 0.f);
+            store4<T>(outz + 32 + 8 * g + 4 * h, 0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
 
     // fragment-major operands (glc_layout.h): one tile = 4 (or 2x2) units of 64 lanes x 16 B
     const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Qh) + ((size_t)bh * Sp + q0) * 64 + lane * 8;

@@ -330,6 +330,14 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restri
     const T* __restrict__ Vp = Vt + ((size_t)(b * nkv + g) * nt * ND * 2) * 512 + lane * 8;
     const float* __restrict__ kb = kbias + (size_t)b * Sp;
 
+    if (q0 >= klen[b] && q0 > 0) {           // padding-only query tile of a ragged batch: no attended row reads it; store zeros
+        T* outz = CTX + ((size_t)b * Sp + q0 + c) * ((size_t)nq * D) + (size_t)hq * D;
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) store4<T>(outz + 32 * a + 8 * gq + 4 * h, 0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     int nkt = (klen[b] + 31) >> 5;
     nkt = nkt < 1 ? 1 : (nkt > nt ? nt : nkt);
     if (causal && nkt > qt + 1) nkt = qt + 1;

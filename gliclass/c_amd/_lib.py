@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("GLC_HIP_SO") or os.path.join(_HERE, "libgliclass_hip.so")   # override: developer A/B of two builds
-MODEL_SO = os.path.join(_HERE, "libgliclass_model.so")
+MODEL_SO = os.environ.get("GLC_MODEL_SO") or os.path.join(_HERE, "libgliclass_model.so")   # override: sanitizer build of the host layer
 
 
 class ModelConfig(C.Structure):

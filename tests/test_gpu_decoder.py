@@ -51,6 +51,27 @@ def test_decoder_live_oracle_sweep(dtype, weights_for, sweep_refs):
         eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_decoder_head_dim_64_and_long_sequence(dtype, weights_for):
+    """head_dim 64 (the D = 64 instantiation of the layout pass and of the MFMA kernel) with 4 query / 2 kv heads, and a
+    sequence longer than any fixture (S = 2500: RoPE table, 79 key tiles, diagonal tile in the last partial 64-block)."""
+    import oracle_c
+    from gliclass.c_amd import synth, weights
+    from gliclass.c_amd.engine import Engine
+    base, _ = weights_for("dec-tiny")
+    cfg = dataclasses.replace(base, head_dim=64, heads=4, kv_heads=2, layers=2)
+    w = weights.make_weights(cfg, 11)
+    eng = Engine(cfg, w, dtype=dtype)
+    try:
+        for (B, S, seed) in ((3, 150, 1), (1, 2500, 2)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, 3, seed=seed, ragged=True)
+            ref = oracle_c.forward(cfg, w, ids, mask)
+            got = eng.forward(ids, mask)
+            assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (B, S)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("variant", ["bidirectional", "first-pooling", "mha"])
 def test_decoder_config_switches(variant, weights_for):
     """causal = 0 (the LLM2Vec-style bidirectional wrapping, unpinned upstream), pooling = 'first', and kv_heads = heads

@@ -388,3 +388,33 @@ def test_length_bucketing_preserves_results(dtype, engines, weights_for):
             ref = oracle_c.forward(cfg, w, ids[b:b + 1, :n], mask[b:b + 1, :n])
             k = ref.shape[1]
             assert np.abs(sig(got[b, :k]) - sig(ref[0])).max() <= TOL_PROB["f32"]
+
+
+@pytest.mark.parametrize("cname", ["tiny", "dec-tiny"])
+def test_randomised_shape_sweep(cname, engines, weights_for):
+    """Seeded random shapes for both backbones in the parity-grade mode: B in 1..9, S in 1..700 (any residue mod 32/64), 0..6
+    labels per row, ragged lengths incl. rows that are almost empty, and a mask hole inside a row (attended tokens after a
+    masked one).  Each case is checked against the oracle; a failure prints the case so it can be replayed."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for(cname)
+    eng = engines(cname, "f32")
+    rng = np.random.default_rng(20261003)
+    for case in range(24):
+        B = int(rng.integers(1, 10))
+        S = int(rng.integers(1, 701)) if case % 6 else int(rng.integers(1, 40))
+        Cmax = int(rng.integers(0, 7))
+        lpr = [int(x) for x in rng.integers(0, Cmax + 1, size=B)]
+        need = 2 + 3 * max(lpr + [0]) + 2
+        if S < need:
+            S = need
+        ids, mask, counts = synth.make_inputs(cfg, B, S, max(Cmax, 1), seed=1000 + case, ragged=bool(case % 2), labels_per_row=lpr)
+        if case % 5 == 0 and S > 20:                       # a hole: masked tokens in the middle of row 0
+            n0 = int(mask[0].sum())
+            if n0 > 16:
+                mask[0, n0 // 2: n0 // 2 + 3] = 0
+        ref = oracle_c.forward(cfg, w, ids, mask)
+        got = eng.forward(ids, mask)
+        assert got.shape == ref.shape, (case, B, S, lpr)
+        if ref.size:
+            assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB["f32"], (case, B, S, lpr)

@@ -390,15 +390,16 @@ def test_length_bucketing_preserves_results(dtype, engines, weights_for):
             assert np.abs(sig(got[b, :k]) - sig(ref[0])).max() <= TOL_PROB["f32"]
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("cname", ["tiny", "dec-tiny"])
-def test_randomised_shape_sweep(cname, engines, weights_for):
-    """Seeded random shapes for both backbones in the parity-grade mode: B in 1..9, S in 1..700 (any residue mod 32/64), 0..6
+def test_randomised_shape_sweep(cname, dtype, engines, weights_for):
+    """Seeded random shapes for both backbones, in the parity-grade mode and in f16 (the MFMA attention kernels): B in 1..9, S in 1..700 (any residue mod 32/64), 0..6
     labels per row, ragged lengths incl. rows that are almost empty, and a mask hole inside a row (attended tokens after a
     masked one).  Each case is checked against the oracle; a failure prints the case so it can be replayed."""
     import oracle_c
     from gliclass.c_amd import synth
     cfg, w = weights_for(cname)
-    eng = engines(cname, "f32")
+    eng = engines(cname, dtype)
     rng = np.random.default_rng(20261003)
     for case in range(24):
         B = int(rng.integers(1, 10))
@@ -417,4 +418,4 @@ def test_randomised_shape_sweep(cname, engines, weights_for):
         got = eng.forward(ids, mask)
         assert got.shape == ref.shape, (case, B, S, lpr)
         if ref.size:
-            assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB["f32"], (case, B, S, lpr)
+            assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (case, B, S, lpr)

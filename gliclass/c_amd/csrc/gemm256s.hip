@@ -350,6 +350,19 @@ const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmAr
     return dtype == GLC_DT_BF16 ? launch_t<bf16_t>(st, epi, a) : launch_t<f16_t>(st, epi, a);
 }
 
+bool glc_gemm_small_m(const GemmArgs& a) {
+    static const int mode = getenv("GLC_GEMM_SMALL_M") ? atoi(getenv("GLC_GEMM_SMALL_M")) : 1;     // developer A/B switch (0 = off)
+    if (!mode) return false;
+    static std::atomic<int> ncu_cache{0};
+    int ncu = ncu_cache.load(std::memory_order_relaxed);
+    if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        ncu_cache.store(ncu, std::memory_order_relaxed);
+    }
+    return (long long)(a.Mpad / TM) * (a.N / TN) * 2 < ncu;
+}
+
 bool glc_gemm_use_stagger() {
     static const bool on = getenv("GLC_GEMM_STAGGER") == nullptr || atoi(getenv("GLC_GEMM_STAGGER")) != 0;   // default on; GLC_GEMM_STAGGER=0 -> gemm256.hip
     return on;

@@ -30,10 +30,14 @@ bool glc_gemm256_supported(int dtype, const GemmArgs& a);
 const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a);    // 256x256 tile, 16-bit T
 const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmArgs& a);   // 256x256 tile, staggered wave groups (gemm256s.hip)
 bool glc_gemm_use_stagger();
+bool glc_gemm_small_m(const GemmArgs& a);   // gemm256s.hip: too few 256x256 tiles for this device -> use the 128x128 kernel
 // picks the 256x256 LDS-DMA kernel when the shape allows it, else the 128x128 one
 inline const char* glc_launch_gemm_auto(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
     const bool qkv_ok = epi != EPI_QKV || a.H % 256 == 0;
     if (!(glc_gemm256_supported(dtype, a) && qkv_ok)) return glc_launch_gemm(st, dtype, epi, a);
+    // Small M (the reference's own batches of 8 short texts): too few 256x256 tiles to cover the CUs, and each tile runs its
+    // whole K loop alone — the 128x128 kernel gives 4x the workgroups.  Threshold: fewer 256-tiles than half the CUs.
+    if (glc_gemm_small_m(a)) return glc_launch_gemm(st, dtype, epi, a);
     return glc_gemm_use_stagger() ? glc_launch_gemm256s(st, dtype, epi, a) : glc_launch_gemm256(st, dtype, epi, a);
 }
 

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
-        band_store(c2p_l + c * LROW + (((kt_a - 1) & 1) << 5), bacc);
+        band_store(c2p_l + c * LROW + 32, bacc);            // ring half 1: the high block of the first band tile (step 0)
         d = block_delta(kt_a);
         load_pk(d, pk);
         load_pq(d, PQ[0]);
@@ -264,12 +264,14 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
-        band_store(c2p_l + c * LROW + ((kt_a & 1) << 5), bacc);
+        band_store(c2p_l + c * LROW, bacc);                 // ring half 0: its low block
         load_tile(Kp, kt_a, KF[0]);
     }
     int d_next = block_delta(kt_a + 1 < kt_b ? kt_a + 1 : kt_a);
 
-    auto band_tile = [&](int kt, frag_t (&kf)[4], frag_t (&n_kf)[4], frag_t (&pq_lo)[4], frag_t (&pq_hi)[4], frag_t (&n_pq)[4]) {
+    // xr = 32 * (step parity): the ring half that holds this tile's low block.  It follows the STEP (a compile-time constant in
+    // the unrolled loop), not the tile index, so on even steps the c2p gather addresses are lane base + immediate.
+    auto band_tile = [&](int kt, const int xr, frag_t (&kf)[4], frag_t (&n_kf)[4], frag_t (&pq_lo)[4], frag_t (&pq_hi)[4], frag_t (&n_pq)[4]) {
         // ---- prefetch the next tile's operands (clamped re-load on the last tile) ----
         const int ktn = kt + 1 < kt_b ? kt + 1 : kt;
         clk.start();
@@ -303,7 +305,6 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         wave_lds_sync();
         clk.mark(1);
 
-        const int xr = (kt & 1) << 5;           // ring half that holds this tile's low block
         float sv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         clk.stop();
     };
 #define GLC_BAND_STEP(J)                                                                               \
-    band_tile(kt, KF[(J) & 1], KF[((J) + 1) & 1], PQ[(J) % 3], PQ[((J) + 2) % 3], PQ[((J) + 1) % 3]); \
+    band_tile(kt, ((J) & 1) << 5, KF[(J) & 1], KF[((J) + 1) & 1], PQ[(J) % 3], PQ[((J) + 2) % 3], PQ[((J) + 1) % 3]); \
     if (++kt >= kt_b) break;
     if constexpr (UNROLL6) {
         for (int kt = kt_a;;) {
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         }
     } else {                                   // rolled form: slide by copying the fragment sets
         for (int kt = kt_a; kt < kt_b; ++kt) {
-            band_tile(kt, KF[0], KF[1], PQ[0], PQ[2], PQ[1]);
+            band_tile(kt, ((kt - kt_a) & 1) << 5, KF[0], KF[1], PQ[0], PQ[2], PQ[1]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) { PQ[2][s] = PQ[0][s]; PQ[0][s] = PQ[1][s]; KF[0][s] = KF[1][s]; }
         }

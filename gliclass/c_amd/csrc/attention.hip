@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     const T* __restrict__ PKp = reinterpret_cast<const T*>(a.PK) + (size_t)hh * a.P * 64 + 32 * 8 * h;
     const T* __restrict__ PQp = reinterpret_cast<const T*>(a.PQ) + (size_t)hh * a.P * 64 + 32 * 8 * h;
     const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
-    const int32_t* __restrict__ dtab = a.dtab;
     float* c2p_l = lds + (size_t)wave * 2 * 32 * LROW;
     float* p2c_l = c2p_l + 32 * LROW;
 
@@ -104,24 +103,25 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     const int foff = 8 * h;                                        // fragment k-offset of this lane half
 
     // delta of row c of relative-distance block L(t): rel = q0 - 32 t - 31 + c  (t = -1 is the block above tile 0)
-    auto block_delta = [&](int t) -> int {
-        int idx = q0 - 32 * t - 31 + c + Sp - 1;
-        idx = idx < 0 ? 0 : (idx > 2 * Sp - 2 ? 2 * Sp - 2 : idx);
-        return dtab[idx];
-    };
+    // Position-row addressing.  otab (host-built per Sp, engine.hip) maps a relative distance q - k, entry (q - k) + Sp - 1 + 64,
+    // to the BYTE offsets of row delta(q - k) in the PQ (x) and PK (y) fragment layouts; the 64 entries of padding on each side
+    // repeat the clamped ends, so a block of 32 consecutive distances needs one 8-byte load per lane and no clamp / shift / pi math.
+    // Row c of relative-distance block L(t) is rel = q0 - 32 t - 31 + c  (t = -1 is the block above tile 0).
+    const int2* __restrict__ otab = a.otab + (q0 - 31 + c + Sp - 1 + 64);
+    auto block_delta = [&](int t) -> int2 { return otab[-32 * t]; };
     auto load_tile = [&](const T* base, int tile, frag_t (&f)[4]) {      // K tile / Q tile: 4 contiguous 1-KiB units
 #pragma unroll
         for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + (size_t)tile * 2048 + s * 512);
     };
-    auto load_pq = [&](int d, frag_t (&f)[4]) {                           // row d of query_proj(rel): Q layout
-        const T* p = PQp + (size_t)(d >> 5) * 2048 + (d & 31) * 8;
+    auto load_pq = [&](int2 d, frag_t (&f)[4]) {                          // row of query_proj(rel): Q layout
+        const char* p = reinterpret_cast<const char*>(PQp) + d.x;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 512);
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 1024);
     };
-    auto load_pk = [&](int d, frag_t (&f)[4]) {                           // row d of key_proj(rel): K layout (pi on the row)
-        const T* p = PKp + (size_t)(d >> 5) * 2048 + glc_pi32(d & 31) * 8;
+    auto load_pk = [&](int2 d, frag_t (&f)[4]) {                          // row of key_proj(rel): K layout (pi on the row)
+        const char* p = reinterpret_cast<const char*>(PKp) + d.y;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 512);
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 1024);
     };
     auto band_store = [&](float* dst, const f32x16& v) {           // 4 consecutive rr per register group
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     {
         frag_t pk[4];
         f32x16 bacc;
-        int d = block_delta(kt_a - 1);
+        int2 d = block_delta(kt_a - 1);
         load_pk(d, pk);
         load_pq(d, PQ[2]);                   // step 0: low = PQ[0], high = PQ[2]
 #pragma unroll
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         band_store(c2p_l + c * LROW, bacc);                 // ring half 0: its low block
         load_tile(Kp, kt_a, KF[0]);
     }
-    int d_next = block_delta(kt_a + 1 < kt_b ? kt_a + 1 : kt_a);
+    int2 d_next = block_delta(kt_a + 1 < kt_b ? kt_a + 1 : kt_a);
 
     // xr = 32 * (step parity): the ring half that holds this tile's low block.  It follows the STEP (a compile-time constant in
     // the unrolled loop), not the tile index, so on even steps the c2p gather addresses are lane base + immediate.
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
         clk.start();
         load_tile(Kp, ktn, n_kf);
         load_pq(d_next, n_pq);
-        const int d_pk = d_next;
+        const int2 d_pk = d_next;
         d_next = block_delta(kt + 2 < kt_b ? kt + 2 : ktn);
 
         // ---- S^T = K Q^T ; reg i <-> key k0 + 16*(i>>3) + 8h + (i&7) ----
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void attn_simple_kernel(AttnArgs a) {
 // Q/K/V^T/PQ/PK in the fragment-major layouts of glc_layout.h.
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a) {
     if ((!a.Qh && !a.Qrow) || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.kfirst || !a.CTX) return "attention: null pointer";
+    if (impl == 2 && !a.otab) return "attention: the band kernel needs the offset table";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention: bad shape";
     if (impl == 2 && dtype == GLC_DT_F32) return "attention: the MFMA band kernel needs 16-bit operands";
     if (impl == 2 && (a.sel_b || !a.Qh)) return "attention: the band kernel takes no row selection";

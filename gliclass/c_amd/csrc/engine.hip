@@ -17,6 +17,7 @@
 
 #include "../../../include/gliclass_hip.h"
 #include "glc_kernels.h"
+#include "glc_layout.h"
 
 namespace {
 
@@ -86,6 +87,7 @@ struct glc_engine {
     int64_t *d_ids = nullptr, *d_mask = nullptr;
     float *Gt = nullptr, *G1t = nullptr, *G2t = nullptr, *d_logits = nullptr;   // head rows: [text | class] groups, 128-aligned
     std::map<int, int32_t*> dtabs;
+    std::map<int, int2*> otabs;                // Sp -> byte offsets of the PQ / PK rows per relative distance (band kernel, 16-bit)
     std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
     // last forward
     int lastB = 0, lastS = 0, lastSp = 0;
@@ -249,6 +251,21 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         if (!d) return false;
         if (hipMemcpy(d, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { set_err("dtab upload failed"); return false; }
         e->dtabs[Sp] = d;
+        if (e->dtype != GLC_F32) {
+            // band-kernel addressing table: entry j <-> relative distance clamp(j - 64, 0, 2Sp-2) - (Sp-1); x = byte offset of PQ row
+            // delta in the Q fragment layout, y = byte offset of PK row delta in the K layout (pi on the row) — glc_layout.h
+            std::vector<int2> o(t.size() + 128);
+            for (size_t j = 0; j < o.size(); ++j) {
+                const long long r = (long long)j - 64;
+                const int dl = t[r < 0 ? 0 : (r > (long long)t.size() - 1 ? t.size() - 1 : (size_t)r)];
+                o[j].x = ((dl >> 5) * 2048 + (dl & 31) * 8) * 2;
+                o[j].y = ((dl >> 5) * 2048 + glc_pi32(dl & 31) * 8) * 2;
+            }
+            int2* od = (int2*)dmalloc(e, o.size() * sizeof(int2), false);
+            if (!od) return false;
+            if (hipMemcpy(od, o.data(), o.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { set_err("otab upload failed"); return false; }
+            e->otabs[Sp] = od;
+        }
         // saturation points of the table: delta == P-1 for every q-k >= rsat_pos, delta == 0 for every q-k <= rsat_neg
         int rp = Sp, rn = -Sp;
         for (int r = Sp - 1; r >= -(Sp - 1) && t[r + Sp - 1] == 2 * (c.pos_buckets > 0 ? c.pos_buckets : c.max_rel_pos) - 1; --r) rp = r;
@@ -365,6 +382,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
+        a.otab = dt != GLC_F32 ? e->otabs[Sp] : nullptr;
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
@@ -397,7 +415,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         if (band_sel) {
             AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-            a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag;
+            a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp];
             KCHK(glc_launch_attention(st, dt, 2, a), false);
             KCHK(glc_launch_gather_sel(st, dt, e->CTX, e->sel_b, e->sel_q, e->CTXs, R, Sp, H), false);
         } else {
@@ -979,7 +997,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const int B = e->lastB, Sp = e->lastSp, H = e->cfg.hidden, nh = e->cfg.heads;
     const LayerW& w = e->layers[0];
     AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant;
+    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant; a.otab = e->otabs[Sp];
     hipStream_t st = e->stream;
     for (int i = 0; i < 2; ++i) KCHK(glc_launch_attention(st, e->dtype, 2, a), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);

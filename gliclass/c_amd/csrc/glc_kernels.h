@@ -74,6 +74,7 @@ struct AttnArgs {
     const unsigned char* tile_flag = nullptr;         // band kernel: [B, Sp/32] — process only query tiles whose flag is set
     const int* sel_b = nullptr; const int* sel_q = nullptr; const void* Qrow = nullptr; int nsel = 0;
     // band kernel, diagnostic build only: per (block < 64, wave) cycle sums of the band-tile segments [8] (s_memtime ticks)
+    const int2* otab = nullptr;                       // band kernel: [2*Sp-1+128] byte offsets of row delta(q-k) in PQ (x) / PK (y), 64 clamped entries each side
     unsigned long long* stamps = nullptr;
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
 };

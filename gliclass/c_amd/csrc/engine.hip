@@ -65,6 +65,7 @@ struct glc_engine {
     bool prune_last = true;         // last layer only on the rows the head reads (exact)
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
+    float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::vector<void*> allocs;      // everything freed at destroy
@@ -159,6 +160,11 @@ bool upload_as(glc_engine* e, const float* src, size_t n, void* dst, float* stag
 
 bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     const glc_model_config& c = e->cfg;
+    if (!e->splitk_ws) {
+        e->splitk_ws_bytes = (size_t)64 << 20;
+        e->splitk_ws = (float*)dmalloc(e, e->splitk_ws_bytes, false);
+        if (!e->splitk_ws) { e->splitk_ws_bytes = 0; return false; }
+    }
     const int Sp = round_up(S, 64), M = B * Sp, Mpad = round_up(M, 256);
     const size_t es = esize(e->dtype);
     const bool dec = c.backbone == GLC_BACKBONE_DECODER;
@@ -275,6 +281,16 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     return true;
 }
 
+// GEMM launches of the forward carry the engine's split-K workspace (used only when a shape has too few tiles, gemm.hip)
+const char* launch_gemm_auto(glc_engine* e, int dt, int epi, GemmArgs a) {
+    a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes;
+    return glc_launch_gemm_auto(e->stream, dt, epi, a);
+}
+const char* launch_gemm128(glc_engine* e, int dt, int epi, GemmArgs a) {
+    a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes;
+    return glc_launch_gemm(e->stream, dt, epi, a);
+}
+
 // Decoder-style backbone: one launch sequence per batch (Q2:384-398).  Pre-norm residual stream X (operand type T).
 bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, int C, float* d_logits) {
     const glc_model_config& c = e->cfg;
@@ -303,7 +319,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln1, c.ln_eps, M, H), false); }                        // Q2:280
         GemmArgs g;
         g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H;
-        { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, g), false);                                           // Q2:206-208
+        { Prof p(e, PC_QKV); KCHK(launch_gemm_auto(e, dt, EPI_BIAS, g), false);                                           // Q2:206-208
           if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
           else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
         { Prof p(e, PC_ATTN);
@@ -311,17 +327,17 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
           else KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ;
-        { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false); }                                   // Q2:233, :291
+        { Prof p(e, PC_ATTN_OUT); KCHK(launch_gemm_auto(e, dt, EPI_RESID, o), false); }                                   // Q2:233, :291
         std::swap(X, Xn);
         { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
         { Prof p(e, PC_FFN1);                                                                                                  // Q2:47 silu(gate) * up
           if (e->fused_swiglu) { f1.C = e->FF; KCHK(glc_launch_gemm256s(st, dt, EPI_SWIGLU, f1), false); }
-          else { KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); } }
+          else { KCHK(launch_gemm_auto(e, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); } }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false); }
+        { Prof p(e, PC_FFN2); KCHK(launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         std::swap(X, Xn);
         if (e->keep_hidden && l + 1 < L)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
@@ -337,9 +353,9 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         GemmArgs h;
         h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
         h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
-        KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
+        KCHK(launch_gemm128(e, GLC_F32, EPI_GELU, h), false);
         h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
-        KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
+        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, h), false);
         KCHK(glc_launch_head_score(st, e->G2t, e->G2t + (size_t)rt * H, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
     }
     HIPCHK(hipGetLastError(), false);
@@ -378,7 +394,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
         if (last) break;
-        { Prof p(e, PC_QKV); KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false); }
+        { Prof p(e, PC_QKV); KCHK(launch_gemm_auto(e, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
@@ -386,14 +402,14 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
-        { Prof p(e, PC_ATTN_OUT); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false); }
+        { Prof p(e, PC_ATTN_OUT); KCHK(launch_gemm_auto(e, dt, EPI_RESID, o), false); }
         { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
-        { Prof p(e, PC_FFN1); KCHK(glc_launch_gemm_auto(st, dt, EPI_GELU, f1), false); }
+        { Prof p(e, PC_FFN1); KCHK(launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        { Prof p(e, PC_FFN2); KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false); }
+        { Prof p(e, PC_FFN2); KCHK(launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
         if (e->keep_hidden)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
@@ -410,7 +426,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = band_sel ? 0 : 1;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
-        KCHK(glc_launch_gemm_auto(st, dt, EPI_QKV, g), false);
+        KCHK(launch_gemm_auto(e, dt, EPI_QKV, g), false);
         if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)B * (Sp >> 5), st), false);
         KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         if (band_sel) {
@@ -421,21 +437,21 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         } else {
             GemmArgs gq;     // Q rows of the selection: the first H rows of the fused [3H,H] weight are the (pre-scaled) query projection
             gq.A = e->Xs; gq.W = w.Wqkv; gq.bias = w.bqkv; gq.C = e->Qs; gq.Mpad = Rpad; gq.N = H; gq.K = H;
-            KCHK(glc_launch_gemm_auto(st, dt, EPI_BIAS, gq), false);
+            KCHK(launch_gemm_auto(e, dt, EPI_BIAS, gq), false);
             AttnArgs a{nullptr, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTXs, B, nh, Sp, H, e->P};
             a.sel_b = e->sel_b; a.sel_q = e->sel_q; a.Qrow = e->Qs; a.nsel = R;
             KCHK(glc_launch_attention(st, dt, 1, a), false);
         }
         GemmArgs o;
         o.A = e->CTXs; o.W = w.Wo; o.bias = w.bo; o.C = e->T1s; o.resid = e->Xs; o.Mpad = Rpad; o.N = H; o.K = H;
-        KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, o), false);
+        KCHK(launch_gemm_auto(e, dt, EPI_RESID, o), false);
         KCHK(glc_launch_layernorm(st, dt, e->T1s, e->H1s, w.ln1g, w.ln1b, c.ln_eps, R, H), false);
         GemmArgs f1;
         f1.A = e->H1s; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FFs; f1.Mpad = Rpad; f1.N = I; f1.K = H;
-        KCHK(glc_launch_gemm_auto(st, dt, EPI_GELU, f1), false);
+        KCHK(launch_gemm_auto(e, dt, EPI_GELU, f1), false);
         GemmArgs f2;
         f2.A = e->FFs; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1s; f2.resid = e->H1s; f2.Mpad = Rpad; f2.N = H; f2.K = I;
-        KCHK(glc_launch_gemm_auto(st, dt, EPI_RESID, f2), false);
+        KCHK(launch_gemm_auto(e, dt, EPI_RESID, f2), false);
         KCHK(glc_launch_layernorm(st, dt, e->T1s, e->Xs, w.ln2g, w.ln2b, c.ln_eps, R, H), false);
     }
     if (C > 0) {
@@ -451,9 +467,9 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs h;
         h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
         h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
-        KCHK(glc_launch_gemm(st, GLC_F32, EPI_GELU, h), false);
+        KCHK(launch_gemm128(e, GLC_F32, EPI_GELU, h), false);
         h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
-        KCHK(glc_launch_gemm(st, GLC_F32, EPI_BIAS, h), false);
+        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, h), false);
         KCHK(glc_launch_head_score(st, e->G2t, e->G2t + (size_t)rt * H, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
     }
     HIPCHK(hipGetLastError(), false);

@@ -13,6 +13,8 @@
 // consecutive columns n) so each lane stores 4 packed elements; the V third of the fused QKV GEMM
 // flips the operands (lane = n, regs = 4 consecutive m) to write V transposed.  Q, K and V^T leave
 // this kernel in the fragment-major layouts of glc_layout.h (what the attention MFMAs load).
+#include <stdlib.h>
+#include <atomic>
 #include "glc_common.h"
 #include "glc_kernels.h"
 #include "glc_layout.h"
@@ -23,8 +25,8 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 128;          // bytes of K per row per stage
 constexpr int ROWP = ROWB + 16;    // padded LDS row stride (bytes)
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+template <typename T, int EPI, bool SPLITK = false>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
     typedef typename Frag<T>::type frag_t;
     constexpr int BK = ROWB / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * ROWP];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 
     // staging map: thread -> 16-B chunk cc of rows (tid>>3) + 32*i
     const int cc = tid & 7, srow = tid >> 3;
-    const T* ga = A + (size_t)(m0 + srow) * K + cc * (16 / (int)sizeof(T));
+    const T* ga = A + (size_t)(m0 + srow) * K + cc * (16 / (int)sizeof(T));       // advanced to this block's K range below
     const T* gw = W + (size_t)(n0 + srow) * K + cc * (16 / (int)sizeof(T));
     const size_t gstep = (size_t)32 * K;
     u32x4 ra[4], rw[4];
@@ -55,7 +57,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    const int nk_all = K / BK;
+    const int per = SPLITK ? (nk_all + ksplit - 1) / ksplit : nk_all;       // K stages of this block: [kbeg, kbeg + nk)
+    const int kbeg = SPLITK ? (int)blockIdx.z * per : 0;
+    const int nk = SPLITK ? (kbeg + per <= nk_all ? per : (nk_all > kbeg ? nk_all - kbeg : 0)) : nk_all;
+    ga += (size_t)kbeg * BK;
+    gw += (size_t)kbeg * BK;
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -71,8 +78,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         }
     };
 
-    gload(0);
-    sstore(0);
+    if (nk > 0) { gload(0); sstore(0); }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -104,6 +110,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         cur ^= 1;
     }
 
+    if constexpr (SPLITK) {
+        // raw fp32 partial tile -> ws[z][m][n]; bias / activation / residual are applied by splitk_reduce_kernel
+        float* wsz = p.ws + (size_t)blockIdx.z * p.Mpad * N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + r16, n = n0 + wn * 64 + j * 16 + 4 * g;
+                *reinterpret_cast<f32x4*>(wsz + (size_t)m * N + n) = acc[j][i];
+            }
+        return;
+    }
     // ---------------- epilogue ----------------
     const float* __restrict__ bias = grp2 ? p.bias2 : p.bias;
     const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;   // block-uniform (scalar) division
@@ -162,14 +180,71 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
+// Second pass of the split-K path: C[m, n .. n+3] = epi(sum_z ws[z][m][n] + bias[n]) in a fixed summation order (deterministic).
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int ksplit) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, nq = (size_t)p.N / 4;
+    if (idx >= (size_t)p.Mpad * nq) return;
+    const int m = (int)(idx / nq), n = (int)(idx - (size_t)m * nq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.ws + (size_t)m * p.N + n);
+    for (int z = 1; z < ksplit; ++z) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.ws + ((size_t)z * p.Mpad + m) * p.N + n);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    const float* bias = (p.W2 != nullptr && m >= p.m_split) ? p.bias2 : p.bias;
+    if (bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n); v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3]; }
+    if (EPI == EPI_GELU) { v[0] = glc_gelu(v[0]); v[1] = glc_gelu(v[1]); v[2] = glc_gelu(v[2]); v[3] = glc_gelu(v[3]); }
+    if (EPI == EPI_RESID) {
+        float r0, r1, r2, r3;
+        load4<T>(reinterpret_cast<const T*>(p.resid) + (size_t)m * p.N + n, r0, r1, r2, r3);
+        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+    }
+    store4<T>(reinterpret_cast<T*>(p.C) + (size_t)m * p.N + n, v[0], v[1], v[2], v[3]);
+}
+
+// Split-K pays when the 128x128 tiles alone leave most CUs idle and the K loop is long: the reference's own batches of 8 short
+// texts give M = B*Sp of ~1 k rows, i.e. 48 tiles for N = 768.  Returns the number of K parts (1 = no split).
+int splitk_parts(int epi, const GemmArgs& a, int nk) {
+    static const int mode = getenv("GLC_GEMM_SPLITK") ? atoi(getenv("GLC_GEMM_SPLITK")) : 1;        // developer A/B switch (0 = off)
+    if (!mode || epi == EPI_QKV || !a.ws || nk < 8) return 1;
+    static std::atomic<int> ncu_cache{0};
+    int ncu = ncu_cache.load(std::memory_order_relaxed);
+    if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        ncu_cache.store(ncu, std::memory_order_relaxed);
+    }
+    const long long tiles = (long long)(a.N / BN) * (a.Mpad / BM);
+    if (tiles * 2 > ncu) return 1;
+    int parts = (int)(ncu / tiles);                       // aim at about one workgroup per CU
+    if (parts > 8) parts = 8;
+    if (parts > nk / 4) parts = nk / 4;                   // keep at least 4 K stages per part
+    while (parts > 1 && (size_t)parts * a.Mpad * a.N * sizeof(float) > a.ws_bytes) --parts;
+    return parts < 2 ? 1 : parts;
+}
+
 template <typename T> void launch_t(hipStream_t st, int epi, const GemmArgs& a) {
     const int nskip = (epi == EPI_QKV && a.qkv_skip_q) ? a.H / BN : 0;   // pruned last layer: K and V^T columns only
     dim3 grid(a.N / BN - nskip, a.Mpad / BM), block(256);
+    const int parts = splitk_parts(epi, a, a.K / (ROWB / (int)sizeof(T)));
+    if (parts > 1) {
+        grid.z = parts;
+        const unsigned rblocks = (unsigned)(((size_t)a.Mpad * (a.N / 4) + 255) / 256);
+        switch (epi) {
+            case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, true>), grid, block, 0, st, a, parts);
+                           hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI_BIAS>), dim3(rblocks), block, 0, st, a, parts); break;
+            case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU, true>), grid, block, 0, st, a, parts);
+                           hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI_GELU>), dim3(rblocks), block, 0, st, a, parts); break;
+            default:       hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID, true>), grid, block, 0, st, a, parts);
+                           hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI_RESID>), dim3(rblocks), block, 0, st, a, parts); break;
+        }
+        return;
+    }
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, a); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU>), grid, block, 0, st, a); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID>), grid, block, 0, st, a); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_QKV>), grid, block, 0, st, a); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, a, 1); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU>), grid, block, 0, st, a, 1); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID>), grid, block, 0, st, a, 1); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_QKV>), grid, block, 0, st, a, 1); break;
     }
 }
 

@@ -24,6 +24,9 @@ struct GemmArgs {
     unsigned long long* stamps = nullptr;   // gemm256 diagnostic build only: per (block<64, wave) cycle sums [compute, dma_wait, barrier_wait, total]
     int spread_dma = 0;                     // gemm256: issue the next stage's DMA between MFMA groups instead of up front
     int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
+    // gemm_nt (128-tile) split-K for small M: the K loop is cut into `ksplit` parts (grid.z), each writes its fp32 partial tile to
+    // ws[z][Mpad][N]; a second pass sums the parts in a fixed order and applies the epilogue.  ws_bytes = capacity of ws.
+    float* ws = nullptr; size_t ws_bytes = 0;
 };
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);

@@ -58,9 +58,12 @@ template <bool ON> struct SegClock {
     __device__ __forceinline__ void mark(int k) { if constexpr (ON) { if (live) { const unsigned t = now(); seg[k] += t - prev; prev = t; } } }
 };
 
+// fp32 (T = float, the parity-grade mode) runs the same code on 32x32x2 fp32 MFMAs; its fragments are twice as large, so it is
+// built for one wave per SIMD (512 VGPRs) with the rolled band loop.
 template <typename T, bool UNROLL6, bool DIAG = false>
-__global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
-    typedef typename Frag<T>::type frag_t;
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(AttnArgs a) {
+    typedef typename AFrag<T>::type frag_t;
+    constexpr int UNITB = 512 * (int)sizeof(T);      // bytes of one fragment unit (64 lanes x 8 elements)
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -116,12 +119,12 @@ __global__ __launch_bounds__(256, 2) void attn_band_kernel(AttnArgs a) {
     auto load_pq = [&](int2 d, frag_t (&f)[4]) {                          // row of query_proj(rel): Q layout
         const char* p = reinterpret_cast<const char*>(PQp) + d.x;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 1024);
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * UNITB);
     };
     auto load_pk = [&](int2 d, frag_t (&f)[4]) {                          // row of key_proj(rel): K layout (pi on the row)
         const char* p = reinterpret_cast<const char*>(PKp) + d.y;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * 1024);
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(p + s * UNITB);
     };
     auto band_store = [&](float* dst, const f32x16& v) {           // 4 consecutive rr per register group
 #pragma unroll
@@ -449,14 +452,16 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     if ((!a.Qh && !a.Qrow) || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.dtab || !a.kbias || !a.klen || !a.kfirst || !a.CTX) return "attention: null pointer";
     if (impl == 2 && !a.otab) return "attention: the band kernel needs the offset table";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention: bad shape";
-    if (impl == 2 && dtype == GLC_DT_F32) return "attention: the MFMA band kernel needs 16-bit operands";
     if (impl == 2 && (a.sel_b || !a.Qh)) return "attention: the band kernel takes no row selection";
     if (impl == 2) {
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
         const size_t dyn = (a.variant & 2) ? 60 * 1024 : 0;     // diagnostic: pad LDS so that one block fits per CU (one wave per SIMD)
         static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: 6x-unrolled band loop (A/B switch)
-        if (a.stamps) {
+        if (dtype == GLC_DT_F32) {
+            if (a.stamps) return "attention: the stamped build exists for f16 only";
+            hipLaunchKernelGGL((attn_band_kernel<float, false>), grid, block, dyn, st, a);
+        } else if (a.stamps) {
             if (dtype != GLC_DT_F16) return "attention: the stamped build exists for f16 only";
             hipLaunchKernelGGL((attn_band_kernel<f16_t, false, true>), grid, block, dyn, st, a);   // rolled loop: room for the stamp registers
         } else if (dtype == GLC_DT_BF16) {

@@ -257,15 +257,15 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         if (!d) return false;
         if (hipMemcpy(d, t.data(), t.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { set_err("dtab upload failed"); return false; }
         e->dtabs[Sp] = d;
-        if (e->dtype != GLC_F32) {
+        {
             // band-kernel addressing table: entry j <-> relative distance clamp(j - 64, 0, 2Sp-2) - (Sp-1); x = byte offset of PQ row
             // delta in the Q fragment layout, y = byte offset of PK row delta in the K layout (pi on the row) — glc_layout.h
             std::vector<int2> o(t.size() + 128);
             for (size_t j = 0; j < o.size(); ++j) {
                 const long long r = (long long)j - 64;
                 const int dl = t[r < 0 ? 0 : (r > (long long)t.size() - 1 ? t.size() - 1 : (size_t)r)];
-                o[j].x = ((dl >> 5) * 2048 + (dl & 31) * 8) * 2;
-                o[j].y = ((dl >> 5) * 2048 + glc_pi32(dl & 31) * 8) * 2;
+                o[j].x = ((dl >> 5) * 2048 + (dl & 31) * 8) * (int)es;
+                o[j].y = ((dl >> 5) * 2048 + glc_pi32(dl & 31) * 8) * (int)es;
             }
             int2* od = (int2*)dmalloc(e, o.size() * sizeof(int2), false);
             if (!od) return false;
@@ -385,7 +385,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
       KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
 
-    const int impl = e->attn_impl ? e->attn_impl : (dt == GLC_F32 ? 1 : 2);
+    const int impl = e->attn_impl ? e->attn_impl : 2;        // MFMA band kernel for every operand type (fp32: 32x32x2 MFMAs); 1 = straightforward kernel
     const bool prune = e->prune_last && !e->keep_hidden && c.pooling == GLC_POOL_FIRST;
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
@@ -398,7 +398,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
-        a.otab = dt != GLC_F32 ? e->otabs[Sp] : nullptr;
+        a.otab = e->otabs[Sp];
         { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
@@ -920,7 +920,6 @@ int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hi
 int glc_engine_set_prune_last_layer(glc_engine* e, int on) { if (!e) return -1; e->prune_last = on != 0; return 0; }
 int glc_debug_set_attention_impl(glc_engine* e, int impl) {
     if (!e || impl < 0 || impl > 2) { set_err("bad attention impl"); return -1; }
-    if (impl == 2 && e->dtype == GLC_F32) { set_err("MFMA attention needs 16-bit operands"); return -1; }
     e->attn_impl = impl;
     return 0;
 }

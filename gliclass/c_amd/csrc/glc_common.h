@@ -49,6 +49,19 @@ __device__ __forceinline__ void mma32(const f16x8& a, const f16x8& b, f32x16& c)
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// Attention operand fragment: 8 consecutive k-elements per lane for every T (one 32x32x16 MFMA for the 16-bit types; for fp32
+// eight 32x32x2 MFMAs — MFMA j pairs k = 8*(l>>5) + j of the two lane halves, identically on both operands, so the fragment-major
+// layouts of glc_layout.h serve fp32 unchanged and the 32x32 result layout is the same).
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <typename T> struct AFrag;
+template <> struct AFrag<bf16_t> { typedef bf16x8 type; };
+template <> struct AFrag<f16_t> { typedef f16x8 type; };
+template <> struct AFrag<float> { typedef f32x8 type; };
+__device__ __forceinline__ void mma32(const f32x8& a, const f32x8& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 

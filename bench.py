@@ -106,6 +106,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if world > 1:      # N ranks on one node generate their synthetic weights at the same time: share the host cores between them
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
     import torch
     dist = None
     if world > 1 or os.environ.get("GLC_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU

@@ -74,11 +74,13 @@ def test_prng_and_tensor_specs_match_python(libs):
         model.glc_prng_fill(42, name.encode(), n, amp, mean, out.ctypes.data)
         assert np.array_equal(out, prng.uniform_f32(42, name, n, amp, mean))
         assert model.glc_fnv1a64(name.encode()) == prng.fnv1a64(name)
-    for cname in ("tiny", "mini", "small", "base", "large"):
+    for cname in ("tiny", "mini", "small", "base", "large", "dec-tiny", "dec-mini", "qwen-1.5b"):
         cfg = CONFIGS[cname]
         cc = _lib.ModelConfig()
         assert model.glc_named_config(cname.encode(), C.byref(cc)) == 0
-        for f in ("vocab", "hidden", "layers", "heads", "inter", "class_token_index", "text_token_index", "pos_buckets"):
+        assert abs(cc.ln_eps - cfg.ln_eps) < 1e-12 and abs(cc.rope_theta - cfg.rope_theta) < 1.0
+        for f in ("vocab", "hidden", "layers", "heads", "head_dim", "inter", "class_token_index", "text_token_index", "pos_buckets",
+                  "backbone", "kv_heads", "causal", "pooling"):
             assert getattr(cc, f) == getattr(cfg, f), (cname, f)
         specs = weights.tensor_specs(cfg)
         buf = C.create_string_buffer(96)
@@ -95,21 +97,25 @@ def test_weight_sources_synthetic_and_blob(libs, tmp_path):
     _lib, hip, model = libs
     from gliclass.c_amd import weights
     from gliclass.c_amd.config import CONFIGS
-    cfg = CONFIGS["tiny"]
-    ref = weights.make_weights(cfg, 7)
-    names = [s[0] for s in weights.tensor_specs(cfg)]
-    path = str(tmp_path / "tiny.glcw")
-    weights.write_blob(path, cfg, ref)
-    cfg2, back = weights.read_blob(path)
-    assert cfg2.hidden == cfg.hidden and all(np.array_equal(back[n], ref[n]) for n in names)
-    for src in (b"synthetic:tiny:7", path.encode()):
-        W = _lib.Weights()
-        assert model.glc_weights_load(src, C.byref(W)) == 0
-        assert W.n_tensors == len(names) and W.cfg.hidden == cfg.hidden and W.cfg.class_token_index == cfg.class_token_index
-        for i, n in enumerate(names):
-            got = np.ctypeslib.as_array(W.tensors[i], shape=(ref[n].size,))
-            assert np.array_equal(got, ref[n].ravel()), n
-        model.glc_weights_free(C.byref(W))
+    for cname in ("tiny", "dec-tiny"):                  # both backbone families; the blob header (v2) carries the family
+        cfg = CONFIGS[cname]
+        ref = weights.make_weights(cfg, 7)
+        names = [s[0] for s in weights.tensor_specs(cfg)]
+        path = str(tmp_path / (cname + ".glcw"))
+        weights.write_blob(path, cfg, ref)
+        cfg2, back = weights.read_blob(path)
+        assert cfg2.hidden == cfg.hidden and cfg2.backbone == cfg.backbone and cfg2.kv_heads == cfg.kv_heads
+        assert cfg2.causal == cfg.causal and abs(cfg2.rope_theta - cfg.rope_theta) < 1.0 and cfg2.pooling == cfg.pooling
+        assert all(np.array_equal(back[n], ref[n]) for n in names)
+        for src in (f"synthetic:{cname}:7".encode(), path.encode()):
+            W = _lib.Weights()
+            assert model.glc_weights_load(src, C.byref(W)) == 0
+            assert W.n_tensors == len(names) and W.cfg.hidden == cfg.hidden and W.cfg.class_token_index == cfg.class_token_index
+            assert W.cfg.backbone == cfg.backbone and W.cfg.kv_heads == cfg.kv_heads and W.cfg.head_dim == cfg.head_dim
+            for i, n in enumerate(names):
+                got = np.ctypeslib.as_array(W.tensors[i], shape=(ref[n].size,))
+                assert np.array_equal(got, ref[n].ravel()), n
+            model.glc_weights_free(C.byref(W))
     W = _lib.Weights()
     assert model.glc_weights_load(b"/nonexistent.glcw", C.byref(W)) != 0
     assert model.glc_weights_load(b"synthetic:nope", C.byref(W)) != 0

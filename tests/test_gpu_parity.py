@@ -256,25 +256,26 @@ def test_pure_c_driver_end_to_end(tmp_path, weights_for):
     assert np.abs(np.array(scores) - np.array(sorted(ref))).max() <= 2e-5      # %.6f printing + fp32 noise
 
 
-def test_checkpoint_import_path_vs_live_hf(tmp_path):
-    """an HF DebertaV2Model state_dict (+ head tensors) -> weights.from_state_dict -> .glcw blob ->
+@pytest.mark.parametrize("cname,prefix", [("mini", "encoder_model.model."), ("dec-mini", "decoder_model.model.")])
+def test_checkpoint_import_path_vs_live_hf(cname, prefix, tmp_path):
+    """an HF DebertaV2Model / Qwen2Model state_dict (+ head tensors) -> weights.from_state_dict -> .glcw blob ->
     create_ort_session(path) -> run_inference, compared with the live HF forward of the SAME module."""
     transformers = pytest.importorskip("transformers")
     import torch
     import hf_ref
     from gliclass.c_amd import _lib, synth, weights
     from gliclass.c_amd.config import CONFIGS
-    cfg = CONFIGS["mini"]
+    cfg = CONFIGS[cname]
     base = weights.make_weights(cfg, 5)
     torch.manual_seed(0)
     model = hf_ref.build_hf_model(cfg, base)
     with torch.no_grad():                                  # perturb so the blob really comes from the module
         for p in model.parameters():
             p.add_(0.01 * torch.randn_like(p))
-    sd = {"encoder_model.model." + k: v for k, v in model.state_dict().items()}   # gliclass-style prefix
+    sd = {prefix + k: v for k, v in model.state_dict().items()}   # gliclass-style prefix
     sd.update({k: torch.from_numpy(v) for k, v in base.items() if "projector" in k})
     tensors = weights.from_state_dict(sd, cfg)
-    path = str(tmp_path / "mini.glcw")
+    path = str(tmp_path / (cname + ".glcw"))
     weights.write_blob(path, cfg, tensors)
     ids, mask, _ = synth.make_inputs(cfg, 3, 90, 3, seed=9, ragged=True)
     ref = hf_ref.forward(cfg, tensors, ids, mask, model=model)

@@ -354,13 +354,11 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restri
         for (int i = 0; i < 16; ++i) o[a][i] = 0.f;
     float m = -3.0e38f, l = 0.f;
 
-    frag_t kf[NS], nkf[NS];
+    frag_t kf[NS];                   // ONE K set: the next tile is loaded into it right after its last MFMA of this tile has issued
 #pragma unroll
     for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const frag_t*>(Kp + s * 512);
     for (int kt = 0; kt < nkt; ++kt) {
         const int ktn = kt + 1 < nkt ? kt + 1 : kt;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) nkf[s] = *reinterpret_cast<const frag_t*>(Kp + (size_t)ktn * NS * 512 + s * 512);
         frag_t vt[ND][2];
 #pragma unroll
         for (int a = 0; a < ND; ++a)
@@ -372,6 +370,8 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restri
         for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) mma32(kf[s], qf[s], sacc);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const frag_t*>(Kp + (size_t)ktn * NS * 512 + s * 512);
         float sv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
@@ -418,8 +418,6 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restri
 #pragma unroll
             for (int a = 0; a < ND; ++a) mma32(vt[a][t], pfr, o[a]);        // O^T[dd = 32a + (i&3) + 8(i>>2) + 4h][query c]
         }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) kf[s] = nkf[s];
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;

@@ -360,6 +360,21 @@ def test_pooling_switches(pooling, weights_for):
         assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], dtype
 
 
+def test_length_bucketing_decoder_backbone(engines, weights_for):
+    """The same bucketing on the decoder backbone (last-token pooling reads each group's own lengths)."""
+    from gliclass.c_amd import synth
+    cfg, _ = weights_for("dec-mini")
+    eng = engines("dec-mini", "f32")
+    B, S = 400, 640                                    # 8 waves of 256-row tiles as one padded batch (hidden 512), ~6 when grouped
+    ids, mask, _ = synth.make_inputs(cfg, B, S, 2, seed=78, ragged=True)
+    eng.set_length_buckets(1)
+    one = eng.forward(ids, mask)
+    eng.set_length_buckets(4)
+    got = eng.forward(ids, mask)
+    assert eng.L.glc_debug_last_forward_groups(eng.h) >= 2
+    assert np.abs(sig(got) - sig(one)).max() <= 1e-5
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_length_bucketing_preserves_results(dtype, engines, weights_for):
     """glc_engine_forward splits a ragged batch into length groups (default 4); every row's logits must equal the single padded

@@ -23,7 +23,8 @@
 // The band SLIDES: stepping one key tile lowers rmin by 32, so the upper 32-row block of tile kt+1 is
 // the lower block of tile kt.  Per key tile only one new block of PK/PQ rows is loaded, the c2p band
 // (a function of (rel, q) only) is computed for that block alone and kept in a 2-slot LDS ring,
-// and the next tile's K / PK / PQ fragments are prefetched under the current tile's MFMAs.
+// and the next tile's K / PK / PQ fragments are loaded under the current tile's work (in the default build straight
+// into the registers of the operands that have just issued their last MFMA: one K set, two PQ sets).
 // Tried and rejected (same-box A/B, see git history "attn_band2"): one wave owning two query tiles at one
 // wave per SIMD (shared K/V/PQ loads, 36 instead of 40 MFMA per tile pair) — bit-identical results but 33 %
 // slower: hipcc's schedule does not overlap the two tiles well enough to replace two-wave TLP.
@@ -60,7 +61,7 @@ template <bool ON> struct SegClock {
 
 // fp32 (T = float, the parity-grade mode) runs the same code on 32x32x2 fp32 MFMAs; its fragments are twice as large, so it is
 // built for one wave per SIMD (512 VGPRs) with the rolled band loop.
-template <typename T, bool UNROLL6, bool DIAG = false>
+template <typename T, bool UNROLL6 /* the lean two-step band loop (default for 16-bit T); false = rolled loop */, bool DIAG = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(AttnArgs a) {
     typedef typename AFrag<T>::type frag_t;
     constexpr int UNITB = 512 * (int)sizeof(T);      // bytes of one fragment unit (64 lanes x 8 elements)
@@ -244,9 +245,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
     sat_tiles(0, kt_a, a.P - 1);
 
     if (kt_a < kt_b) {
-    // Fragment sets are addressed STATICALLY (runtime-indexed register arrays would go to scratch): the K set
-    // alternates with period 2 and the PQ sets rotate with period 3 (low block -> high block -> dead), so the
-    // loop is unrolled 6x and no register copies are needed to slide the band.
+    // Fragment sets are addressed STATICALLY (runtime-indexed register arrays would go to scratch).  The default build
+    // (UNROLL6, band_tile2 below) needs KF[0], PQ[0], PQ[2]; the rolled form (diagnostics, fp32) slides three PQ sets by copying.
     frag_t KF[2][4], PQ[3][4];
     // ---- band prologue: c2p blocks L(kt_a-1), L(kt_a) -> their ring halves; PQ fragments of both; K of tile kt_a ----
     {
@@ -334,12 +334,60 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
         clk.mark(6);
         clk.stop();
     };
-#define GLC_BAND_STEP(J)                                                                               \
-    band_tile(kt, ((J) & 1) << 5, KF[(J) & 1], KF[((J) + 1) & 1], PQ[(J) % 3], PQ[((J) + 2) % 3], PQ[((J) + 1) % 3]); \
-    if (++kt >= kt_b) break;
+    // Lean form of the same tile (the default build): ONE K set and TWO PQ sets, re-loaded IN PLACE as soon as their last
+    // MFMA of this tile has issued (the next K tile into the K set; the next low block into the set that was this tile's high
+    // block), and the c2p MFMAs of the next block issued BEFORE the softmax so the matrix pipe works under its VALU stream.
+    // The roles of the two PQ sets swap every tile, so the loop is unrolled by two.  Same operands, same arithmetic.
+    auto band_tile2 = [&](int kt, const int xr, frag_t (&kf)[4], frag_t (&pq_lo)[4], frag_t (&pq_hi)[4]) {
+        const int ktn = kt + 1 < kt_b ? kt + 1 : kt;
+        frag_t pk[4];
+        load_pk(d_next, pk);                    // PK rows of L(kt+1): consumed right after the gather
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+        {
+            f32x16 bacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pq_lo[s], kf[s], bacc);
+            band_store(p2c_l + c * LROW, bacc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pq_hi[s], kf[s], bacc);
+            band_store(p2c_l + c * LROW + 32, bacc);
+        }
+        load_tile(Kp, ktn, kf);                 // in place: K(kt+1)
+        load_pq(d_next, pq_hi);                 // in place: L(kt+1), the next tile's low block
+        d_next = block_delta(kt + 2 < kt_b ? kt + 2 : ktn);
+        wave_lds_sync();
+        float sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kc = 16 * (i >> 3) + (i & 7);
+            const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);
+            const int rr = rr_base - kc;
+            sv[i] = sacc[i] + c2p_l[c * LROW + (rr ^ xr)] + p2c_l[(prow + 4 * h) * LROW + rr];
+        }
+        f32x16 bacc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc2[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc2);             // c2p of L(kt+1)  [rr][query c]
+        softmax_pv(sv, kt);
+        wave_lds_sync();                        // this tile's gathers retire before the ring slot is overwritten
+        band_store(c2p_l + c * LROW + (xr ^ 32), bacc2);
+    };
     if constexpr (UNROLL6) {
+        // prologue left: KF[0] = K(kt_a), PQ[0] = L(kt_a) (low), PQ[2] = L(kt_a - 1) (high)
         for (int kt = kt_a;;) {
-            GLC_BAND_STEP(0) GLC_BAND_STEP(1) GLC_BAND_STEP(2) GLC_BAND_STEP(3) GLC_BAND_STEP(4) GLC_BAND_STEP(5)
+            band_tile2(kt, 0, KF[0], PQ[0], PQ[2]);
+            if (++kt >= kt_b) break;
+            band_tile2(kt, 32, KF[0], PQ[2], PQ[0]);
+            if (++kt >= kt_b) break;
         }
     } else {                                   // rolled form: slide by copying the fragment sets
         for (int kt = kt_a; kt < kt_b; ++kt) {
@@ -348,7 +396,6 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
             for (int s = 0; s < 4; ++s) { PQ[2][s] = PQ[0][s]; PQ[0][s] = PQ[1][s]; KF[0][s] = KF[1][s]; }
         }
     }
-#undef GLC_BAND_STEP
     }
 
     sat_tiles(kt_b, nkt, 0);
@@ -457,7 +504,7 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
         const size_t dyn = (a.variant & 2) ? 60 * 1024 : 0;     // diagnostic: pad LDS so that one block fits per CU (one wave per SIMD)
-        static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: 6x-unrolled band loop (A/B switch)
+        static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: lean two-step band loop; the env picks the rolled one (A/B)
         if (dtype == GLC_DT_F32) {
             if (a.stamps) return "attention: the stamped build exists for f16 only";
             hipLaunchKernelGGL((attn_band_kernel<float, false>), grid, block, dyn, st, a);

@@ -31,6 +31,10 @@ class OrtValue(C.Structure):
     _fields_ = [("type", C.c_int), ("ndim", C.c_size_t), ("dims", C.c_int64 * 4), ("data", C.c_void_p), ("owns_data", C.c_int)]
 
 
+class TokenizerEncodeResult(C.Structure):
+    _fields_ = [("token_ids", C.POINTER(C.c_int)), ("len", C.c_size_t)]
+
+
 class TokenizedInputs(C.Structure):
     _fields_ = [("input_ids", C.POINTER(C.POINTER(C.c_int))), ("token_type_ids", C.POINTER(C.POINTER(C.c_int))),
                 ("attention_mask", C.POINTER(C.POINTER(C.c_int))), ("batch_size", C.c_size_t), ("seq_length", C.c_size_t)]
@@ -46,7 +50,11 @@ MODEL_SYMBOLS = ["flatten_int_array", "create_tensor", "prepare_input_tensors", 
                  "glc_session_num_devices", "parallel_preprocess", "parallel_postprocess", "sigmoid",
                  "process_output_tensor", "OrtGetApiBase", "g_ort", "glc_weights_load", "glc_weights_free",
                  "glc_prng_fill", "glc_fnv1a64", "glc_named_config", "glc_tensor_spec", "prepare_input", "prepare_inputs",
-                 "free_prepared_inputs"]
+                 "free_prepared_inputs", "tokenizers_new_from_str", "tokenizers_encode", "tokenizers_encode_batch",
+                 "tokenizers_free_encode_results", "tokenizers_decode", "tokenizers_get_decode_str", "tokenizers_get_vocab_size",
+                 "tokenizers_id_to_token", "tokenizers_token_to_id", "tokenizers_free", "glc_tokenizer_normalize",
+                 "tokenize_inputs", "print_tokenized_inputs", "free_tokenized_inputs", "create_tokenizer",
+                 "read_file", "parse_json", "string_to_bool", "free_parsed_data"]
 
 _hip = None
 _model = None
@@ -128,5 +136,29 @@ def model():
         L.glc_fnv1a64.argtypes = [C.c_char_p]
         L.glc_named_config.argtypes = [C.c_char_p, C.POINTER(ModelConfig)]
         L.glc_tensor_spec.argtypes = [C.POINTER(ModelConfig), C.c_int, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.tokenizers_new_from_str.restype = C.c_void_p
+        L.tokenizers_new_from_str.argtypes = [C.c_char_p, C.c_size_t]
+        L.tokenizers_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(TokenizerEncodeResult)]
+        L.tokenizers_encode_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
+                                              C.POINTER(TokenizerEncodeResult)]
+        L.tokenizers_free_encode_results.argtypes = [C.POINTER(TokenizerEncodeResult), C.c_size_t]
+        L.tokenizers_decode.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.c_int]
+        L.tokenizers_get_decode_str.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+        L.tokenizers_get_vocab_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.tokenizers_id_to_token.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.tokenizers_token_to_id.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
+        L.tokenizers_free.argtypes = [C.c_void_p]
+        L.glc_tokenizer_normalize.restype = C.c_void_p
+        L.glc_tokenizer_normalize.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.create_tokenizer.restype = C.c_void_p
+        L.create_tokenizer.argtypes = [C.c_char_p]
+        L.tokenize_inputs.restype = TokenizedInputs
+        L.tokenize_inputs.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t]
+        L.free_tokenized_inputs.argtypes = [C.POINTER(TokenizedInputs)]
+        L.print_tokenized_inputs.argtypes = [C.POINTER(TokenizedInputs)]
+        L.read_file.restype = C.c_void_p
+        L.read_file.argtypes = [C.c_char_p]
+        L.string_to_bool.restype = C.c_bool
+        L.string_to_bool.argtypes = [C.c_char_p]
         _model = L
     return _model

@@ -2,11 +2,10 @@
  * Batch sharding, same interface and chunking rules as /root/reference/src/parallel_processor.c
  * (chunks of BATCH_SIZE texts :28-30, chunk i <-> tensor slot i/BATCH_SIZE :44-45, short last chunk,
  * same_labels selects shared vs per-text label arrays :34-35/:79-81, outputs released after
- * post-processing :88).  Pre-processing needs the prompt builder and the tokenizer, which are outside
- * the hot path: the prompt builder is host/preprocessor.c (weak, so the reference's own
- * src/preprocessor.c may override it); tokenize_inputs is resolved at link time from the integrator's
- * src/tokenizer.c (Rust tokenizers-cpp underneath); when it is absent parallel_preprocess reports that
- * instead of crashing.
+ * post-processing :88).  Pre-processing = prompt builder (host/preprocessor.c) + tokenizer (host/tokenizer.c, the native
+ * Unigram implementation of include/tokenizers_c.h) + prepare_input_tensors.  Both are ordinary exported symbols of this
+ * library, so an integrator who links the reference's own src/preprocessor.c / src/tokenizer.c (+ tokenizers-cpp) into the
+ * executable overrides them.
  */
 #include "parallel_processor.h"
 
@@ -17,8 +16,6 @@
 #include "postprocessor.h"
 #include "preprocessor.h"
 
-__attribute__((weak)) TokenizedInputs tokenize_inputs(TokenizerHandle tokenizer, const char* inputs[], size_t num_texts, size_t max_length);
-__attribute__((weak)) void free_tokenized_inputs(TokenizedInputs* tokenized);
 
 static size_t env_size(const char* name, size_t dflt) {
     const char* s = getenv(name);
@@ -33,8 +30,8 @@ void parallel_preprocess(char** texts, char*** labels, size_t* num_labels, size_
     const size_t bs = env_size("GLICLASS_BATCH_SIZE", BATCH_SIZE), max_len = env_size("GLICLASS_MAX_LENGTH", MAX_LENGTH);
     const size_t nb = (num_texts + bs - 1) / bs;
     for (size_t i = 0; i < nb; ++i) { input_ids_tensors[i] = NULL; attention_mask_tensors[i] = NULL; }
-    if (!tokenize_inputs || !free_tokenized_inputs) {
-        fprintf(stderr, "Error: parallel_preprocess: no tokenizer linked (link the reference's src/tokenizer.c + tokenizers-cpp)\n");
+    if (!tokenizer_handler) {
+        fprintf(stderr, "Error: parallel_preprocess: NULL tokenizer handle\n");
         return;
     }
 #pragma omp parallel for schedule(dynamic)

@@ -1,8 +1,8 @@
 /*
- * Boundary INPUT type of the hot path: the struct `tokenize_inputs` returns in the reference
- * (/root/reference/include/tokenizer.h:13-19, filled at /root/reference/src/tokenizer.c:58-84).
- * The tokenizer itself (Rust tokenizers-cpp) is out of scope; an integrator links
- * the reference's own src/tokenizer.c, which provides tokenize_inputs()/free_tokenized_inputs().
+ * Same interface as /root/reference/include/tokenizer.h:13-25.  `TokenizedInputs` is the boundary INPUT type of the
+ * hot path (filled at /root/reference/src/tokenizer.c:58-84).  The functions are implemented natively in
+ * gliclass/c_amd/host/tokenizer.c on top of include/tokenizers_c.h (no Rust tokenizers-cpp needed); an integrator who
+ * links the reference's own src/tokenizer.c + tokenizers-cpp into the executable overrides them (ELF interposition).
  */
 #ifndef TOKENIZER_H
 #define TOKENIZER_H
@@ -10,9 +10,7 @@
 #include <stdbool.h>
 #include <stddef.h>
 
-#ifndef TOKENIZERS_C_H_
-typedef void* TokenizerHandle; /* tokenizers-cpp's opaque handle (tokenizers_c.h) */
-#endif
+#include "tokenizers_c.h"
 
 typedef struct {
     int** input_ids;      /* [batch_size][seq_length], one malloc per row */
@@ -23,6 +21,8 @@ typedef struct {
 } TokenizedInputs;
 
 TokenizedInputs tokenize_inputs(TokenizerHandle tokenizer, const char* inputs[], size_t num_texts, size_t max_length);
+void print_tokenized_inputs(const TokenizedInputs* tokenized);
 void free_tokenized_inputs(TokenizedInputs* tokenized);
+TokenizerHandle create_tokenizer(const char* filepath);
 
 #endif

@@ -1,0 +1,111 @@
+"""The launcher examples/gliclass_main.c (drop-in for /root/reference/main.c): CPU = front half (JSON -> prompts -> native
+tokenizer) and the loud failure without a GPU; GPU = whole pipeline text -> printed scores against the CPU oracle fed with
+ids from the SAME prompts tokenized by the python path."""
+import dataclasses
+import gzip
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "gliclass", "c_amd", "gliclass_main")
+
+TEXTS = ["One day I will see the world!", "ONNX is an open-source format designed to enable the interoperability of AI models.",
+         "The match ended 3:2 after extra time.", "Der schnelle braune Fuchs springt über den faulen Hund.", "Stocks fell sharply on Monday.",
+         "", "She published a paper on protein folding.", "El veloz murciélago hindú comía feliz cardillo y kiwi.", "Vote on the new budget is due.",
+         "Short.", "A " + "very " * 60 + "long sentence about travelling the world and dreaming of science."]
+LABELS = ["Travel", "dreams", "SPORT", "science", "politics"]
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "gliclass", "c_amd"), "-j4", "all"], stdout=subprocess.DEVNULL)
+    d = tmp_path_factory.mktemp("cli")
+    (d / "tok.json").write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", "tokenizer.json.gz")).read())
+    return d
+
+
+def _write_data(d, same, ctype, name="data.json"):
+    labels = [LABELS] if same else [LABELS[: 1 + i % len(LABELS)] for i in range(len(TEXTS))]
+    (d / name).write_text(json.dumps({"texts": TEXTS, "labels": labels, "same_labels": same, "classification_type": ctype}))
+    return str(d / name), labels
+
+
+def test_usage_and_front_half_without_gpu(workdir):
+    r = subprocess.run([EXE], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.startswith("Usage:")                       # main.c:54-61
+    data, _ = _write_data(workdir, True, "multi-label")
+    r = subprocess.run([EXE, data, "maybe"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid value for bool argument" in r.stdout         # read_data.c:165
+    (workdir / "notype.json").write_text(json.dumps({"texts": ["x"], "labels": [["a"]], "same_labels": True}))
+    r = subprocess.run([EXE, str(workdir / "notype.json"), "true"], capture_output=True, text=True)
+    assert r.returncode == 1 and "classification type is not provided" in r.stdout    # main.c:71-74
+    r = subprocess.run([EXE, data, "true", str(workdir / "missing.json")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Cant open file" in r.stderr                          # tokenizer.c:149
+    from gliclass.c_amd import _lib
+    if _lib.hip().glc_device_count() == 0:
+        r = subprocess.run([EXE, data, "true", str(workdir / "tok.json"), "synthetic:tiny"], capture_output=True, text=True)
+        assert r.returncode == 255 and "DONE: create_tokenizer;" in r.stdout and "no MI355X/HIP device" in r.stderr
+
+
+def _prompts(labels_for, prompt_first):
+    out = []
+    for i, t in enumerate(TEXTS):                                                    # src/preprocessor.c:84-108
+        p = "".join("<<LABEL>>" + l.lower() for l in labels_for(i)) + "<<SEP>>"
+        out.append(p + t if prompt_first else t + p)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("same,prompt_first,ctype", [(True, True, "multi-label"), (False, False, "multi-label"), (True, False, "single-label")])
+def test_launcher_end_to_end_vs_oracle(workdir, same, prompt_first, ctype):
+    import oracle_c
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.tokenizer import Tokenizer
+    cfg = dataclasses.replace(CONFIGS["tiny"], name="tiny-tok", vocab=6003, class_token_index=6001, text_token_index=6002)
+    w = weights.make_weights(cfg, 3)
+    blob = str(workdir / "tiny_tok.glcw")
+    weights.write_blob(blob, cfg, w)
+    data, labels = _write_data(workdir, same, ctype, f"data_{int(same)}{int(prompt_first)}.json")
+    labels_for = (lambda i: labels[0]) if same else (lambda i: labels[i])
+    env = dict(os.environ, GLICLASS_DTYPE="f32", GLICLASS_THRESHOLD="0.0")
+    r = subprocess.run([EXE, data, "true" if prompt_first else "false", str(workdir / "tok.json"), blob], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    for stage in ("parse_json", "create_tokenizer", "initialize_ort_api", "initialize_ort_environment", "create_ort_session"):
+        assert f"DONE: {stage};" in r.stdout
+    assert "Execution time:" in r.stdout
+    # expected: the same prompts, tokenized by the native tokenizer (pinned to HF `tokenizers` in test_tokenizer.py), through the oracle
+    tok = Tokenizer((workdir / "tok.json").read_text())
+    prompts = _prompts(labels_for, prompt_first)
+    want = {}
+    for lo in range(0, len(TEXTS), 8):                                               # BATCH_SIZE chunks (parallel_processor.c:28-30)
+        ids, mask = tok.tokenize_inputs(prompts[lo:lo + 8], 2048)
+        ids, mask = np.array(ids, np.int64), np.array(mask, np.int64)
+        assert ((ids == 6001).sum(1) == [len(labels_for(i)) for i in range(lo, min(lo + 8, len(TEXTS)))]).all()
+        lg = oracle_c.forward(cfg, w, ids, mask)
+        p = 1.0 / (1.0 + np.exp(-lg.astype(np.float64)))
+        for b in range(ids.shape[0]):
+            want[lo + b] = {labels_for(lo + b)[j]: p[b, j] for j in range(len(labels_for(lo + b)))}
+    got, cur = {}, None
+    for line in r.stdout.splitlines():
+        m = re.match(r"Text_(\d+): (.*):$", line)
+        m2 = re.match(r"  Text_(\d+) Label: (.+), Score: ([0-9.]+)$", line)
+        if m2:
+            got.setdefault(("local", int(m2.group(1))), []).append((m2.group(2), float(m2.group(3))))
+    # printed indices are batch-local (postprocessor.c:90): text i of batch k prints as Text_i; collect per (batch, local) by order
+    n_lines = sum(len(v) for v in got.values())
+    if ctype == "multi-label":
+        assert n_lines == sum(len(v) for v in want.values())                         # threshold 0.0: every label printed
+        flat_got = sorted(s for v in got.values() for _, s in v)
+        flat_want = sorted(s for v in want.values() for s in v.values())
+        assert np.abs(np.array(flat_got) - np.array(flat_want)).max() <= 2e-5        # %.6f + fp32
+    else:
+        assert n_lines == len(TEXTS)                                                 # one argmax line per text
+        flat_got = sorted(s for v in got.values() for _, s in v)
+        flat_want = sorted(max(v.values()) for v in want.values())
+        assert np.abs(np.array(flat_got) - np.array(flat_want)).max() <= 2e-5

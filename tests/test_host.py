@@ -39,8 +39,11 @@ def test_every_declared_symbol_is_exported(libs):
     # externally supplied pieces (reference's src/preprocessor.c / src/tokenizer.c) are weak, not exported
     for name in _declared_functions("preprocessor.h"):
         assert hasattr(model, name), name
-    # the tokenizer (Rust tokenizers-cpp behind the reference's src/tokenizer.c) is supplied by the integrator
-    assert _declared_functions("tokenizer.h") == {"tokenize_inputs", "free_tokenized_inputs"}
+    # the native tokenizer (tokenizers-cpp's C API + the reference's src/tokenizer.c surface) and the JSON front-end
+    for hdr in ("tokenizer.h", "tokenizers_c.h", "read_data.h"):
+        for name in _declared_functions(hdr):
+            assert hasattr(model, name), (hdr, name)
+    assert _declared_functions("tokenizer.h") == {"tokenize_inputs", "print_tokenized_inputs", "free_tokenized_inputs", "create_tokenizer"}
 
 
 def test_no_gpu_means_loud_failure(libs):

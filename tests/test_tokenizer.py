@@ -1,0 +1,231 @@
+"""CPU: the native tokenizer (gliclass/c_amd/host/tokenizer.c) against HF `tokenizers` -- the Rust library the reference
+calls through tokenizers-cpp (/root/reference/src/tokenizer.c:33,175).  Golden ids come from
+oracle/gen_tokenizer_fixture.py; when the `tokenizers` wheel is importable the comparison is repeated live on random
+text and on variants of the tokenizer.json (added-token flags, Metaspace options, lower-casing, truncation)."""
+import copy
+import ctypes as C
+import gzip
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def tk_json():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "gliclass", "c_amd"), "-j4", "libgliclass_model.so"], stdout=subprocess.DEVNULL)
+    return gzip.open(os.path.join(GOLD, "tokenizer.json.gz")).read().decode("utf-8")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.loads(gzip.open(os.path.join(GOLD, "tokenizer_golden.json.gz")).read())
+
+
+@pytest.fixture(scope="module")
+def tok(tk_json):
+    from gliclass.c_amd.tokenizer import Tokenizer
+    return Tokenizer(tk_json)
+
+
+def test_normalizer_matches_golden(tok, gold):
+    for t, want in zip(gold["texts"], gold["normalized"]):
+        assert tok.normalize(t) == want, repr(t)
+
+
+def test_ids_match_golden(tok, gold):
+    assert len(gold["texts"]) >= 200
+    for t, want, want_ns in zip(gold["texts"], gold["ids"], gold["ids_no_special"]):
+        assert tok.encode(t, True) == want, repr(t)
+        assert tok.encode(t, False) == want_ns, repr(t)
+
+
+def test_label_tokens_registered_as_special_match_golden(tk_json, gold):
+    """<<LABEL>> / <<SEP>> with normalized=false, special=true: they are cut out of the RAW text and every piece between
+    them is normalised (stripped) on its own."""
+    from gliclass.c_amd.tokenizer import Tokenizer
+    js = json.loads(tk_json)
+    js["added_tokens"] = gold["added_tokens_special_variant"]
+    t2 = Tokenizer(json.dumps(js))
+    for t, want in zip(gold["texts"], gold["ids_special_variant"]):
+        assert t2.encode(t, True) == want, repr(t)
+
+
+def test_batch_api_and_tokenize_inputs(tok, gold):
+    texts = gold["texts"][:64]
+    single = [tok.encode(t) for t in texts]
+    assert tok.encode_batch(texts) == single
+    # /root/reference/src/tokenizer.c:44-84: raw cut at max_length, pad id 0 / mask 0 up to the longest row
+    for max_len in (2048, 16, 1):
+        ids, mask = tok.tokenize_inputs(texts, max_len)
+        S = min(max_len, max(len(s) for s in single))
+        assert len(ids) == len(texts) and all(len(r) == S for r in ids)
+        for row, m, s in zip(ids, mask, single):
+            n = min(len(s), S)
+            assert row[:n] == s[:n] and row[n:] == [0] * (S - n)
+            assert m == [1] * n + [0] * (S - n)
+    over = [s for s in single if len(s) > 16]
+    assert over and all(s[-1] == 2 for s in over)          # ... so the cut at 16 dropped their final [SEP] (kept quirk)
+    ids, mask = tok.tokenize_inputs([], 128)
+    assert ids == [] and mask == []
+
+
+def test_vocab_api_and_decode(tok, tk_json):
+    js = json.loads(tk_json)
+    vocab = js["model"]["vocab"]
+    assert tok.vocab_size() == 6003
+    for i in (0, 1, 2, 3, 4, 100, 5999):
+        assert tok.id_to_token(i) == vocab[i][0]
+        assert tok.token_to_id(vocab[i][0]) == i
+    assert tok.token_to_id("<<LABEL>>") == 6001 and tok.id_to_token(6002) == "<<SEP>>"
+    assert tok.token_to_id("definitely-not-a-piece-☃") == -1
+    ids = tok.encode("Hello world, this is a test.")
+    assert tok.decode(ids, True) == "Hello world, this is a test."
+    assert tok.decode(ids, False).startswith("[CLS]")
+
+
+def test_unsupported_pieces_fail_loudly(tk_json):
+    from gliclass.c_amd.tokenizer import Tokenizer
+    js = json.loads(tk_json)
+    for mutate in (lambda j: j["model"].update(type="BPE"),
+                   lambda j: j.update(normalizer={"type": "NFKC"}),
+                   lambda j: j.update(pre_tokenizer={"type": "ByteLevel"}),
+                   lambda j: j.update(post_processor={"type": "ByteLevel"}),
+                   lambda j: j["normalizer"]["normalizers"].append({"type": "Replace", "pattern": {"Regex": "a|b"}, "content": "x"})):
+        j2 = copy.deepcopy(js)
+        mutate(j2)
+        with pytest.raises(ValueError):
+            Tokenizer(json.dumps(j2))
+    with pytest.raises(ValueError):
+        Tokenizer("{not json")
+    with pytest.raises(ValueError):
+        Tokenizer.from_file("/nonexistent/tokenizer.json")
+
+
+def test_create_tokenizer_from_file(tk_json, gold, tmp_path):
+    from gliclass.c_amd.tokenizer import Tokenizer
+    p = tmp_path / "tokenizer.json"
+    p.write_text(tk_json, encoding="utf-8")
+    t = Tokenizer.from_file(str(p))
+    assert t.encode(gold["texts"][9]) == gold["ids"][9]
+
+
+def test_invalid_utf8_is_replaced_not_crashing(tok):
+    assert tok.encode(b"abc \xff\xfe def \xe2\x82") == tok.encode("abc �� def �")
+
+
+# ------------------------------------------------------------------ live comparison with the Rust library
+
+def _random_texts(n, seed):
+    rnd = random.Random(seed)
+    words = ["the", "quick", "brown", "fox", "jumps", "over", "lazy", "dog", "Hello", "WORLD", "naïve", "café", "über", "straße", "日本語",
+             "中文", "한국어", "привет", "мир", "γειά", "σου", "مرحبا", "नमस्ते", "ｆｕｌｌ", "①②", "ﬁsh", "x²", "½", "é", "ǟ",
+             "<<LABEL>>", "<<SEP>>", "[SEP]", "[CLS]", "[MASK]", "<<LABEL>> ", " <<SEP>>", "😀", "👍🏽", "🇺🇦", "‍", "­", "\t", "\n", "\r\n",
+             "  ", "   ", " ", "　", "▁", "▁▁", ".", ",", "!", "?", "(", ")", "-", "--", "'", "\"", "1", "23", "4.5", "e-7", "0x1F",
+             "http://a.b/c?d=e", "user@mail.com", "don't", "it's", "U.S.A.", "؀", "ः", "각", "️", "⃣", "\U0001f3fd"]
+    out = []
+    for _ in range(n):
+        k = rnd.randint(0, 30)
+        sep = rnd.choice([" ", " ", " ", "", "  "])
+        out.append(sep.join(rnd.choice(words) for _ in range(k)))
+    return out
+
+
+def _variants(js):
+    def v(fn):
+        j = copy.deepcopy(js)
+        fn(j)
+        return j
+    def set_added(j, **kw):
+        for a in j["added_tokens"]:
+            if a["content"] in ("<<LABEL>>", "<<SEP>>", "[MASK]"):
+                a.update(kw)
+    yield "base", js
+    yield "added-lstrip-rstrip", v(lambda j: set_added(j, lstrip=True, rstrip=True))
+    yield "added-special-raw", v(lambda j: set_added(j, normalized=False, special=True))
+    yield "metaspace-never", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(prepend_scheme="never"))
+    yield "metaspace-nosplit", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(split=False))
+    yield "lowercase", v(lambda j: j["normalizer"]["normalizers"].insert(0, {"type": "Lowercase"}))
+    yield "no-normalizer", v(lambda j: j.update(normalizer=None))
+    yield "replace-literal", v(lambda j: j["normalizer"]["normalizers"].append({"type": "Replace", "pattern": {"String": "fox"}, "content": "cat dog"}))
+    yield "no-postprocessor", v(lambda j: j.update(post_processor=None))
+    yield "truncation-12", v(lambda j: j.update(truncation={"direction": "Right", "max_length": 12, "strategy": "LongestFirst", "stride": 0}))
+    yield "truncation-left", v(lambda j: j.update(truncation={"direction": "Left", "max_length": 9, "strategy": "LongestFirst", "stride": 0}))
+
+
+def test_live_against_rust_tokenizers(tk_json):
+    hf = pytest.importorskip("tokenizers")
+    from gliclass.c_amd.tokenizer import Tokenizer
+    texts = _random_texts(400, 11)
+    js = json.loads(tk_json)
+    for name, j in _variants(js):
+        s = json.dumps(j)
+        ref = hf.Tokenizer.from_str(s)
+        mine = Tokenizer(s)
+        for t in texts:
+            for sp in (True, False):
+                assert mine.encode(t, sp) == ref.encode(t, add_special_tokens=sp).ids, (name, repr(t), sp)
+        mine.close()
+
+
+def test_live_byte_fallback(tk_json):
+    hf = pytest.importorskip("tokenizers")
+    from gliclass.c_amd.tokenizer import Tokenizer
+    js = json.loads(tk_json)
+    base = len(js["model"]["vocab"])
+    js["model"]["vocab"] += [["<0x%02X>" % b, -20.0] for b in range(256)]
+    js["model"]["byte_fallback"] = True
+    for a in js["added_tokens"]:
+        if a["id"] >= 6000:
+            a["id"] += 256 + (base - 6001)
+    js["added_tokens"] = [a for a in js["added_tokens"] if a["content"] != "[MASK]"]
+    s = json.dumps(js)
+    ref, mine = hf.Tokenizer.from_str(s), Tokenizer(s)
+    for t in _random_texts(200, 5) + ["☃ snowman \U0001f984 unicorn", "ʘʘʘ"]:
+        assert mine.encode(t) == ref.encode(t).ids, repr(t)
+
+
+# ------------------------------------------------------------------ JSON front-end (read_data.h)
+
+def _parse(model, doc, same_default=False):
+    texts, labels, nl = C.POINTER(C.c_char_p)(), C.POINTER(C.POINTER(C.c_char_p))(), C.POINTER(C.c_size_t)()
+    nt, nls, same, ct = C.c_size_t(0), C.c_size_t(0), C.c_bool(same_default), C.c_char_p()
+    model.parse_json(doc.encode("utf-8"), C.byref(texts), C.byref(nt), C.byref(labels), C.byref(nl), C.byref(nls), C.byref(same), C.byref(ct))
+    out = {"num_texts": nt.value, "same": same.value, "type": ct.value.decode() if ct.value is not None else None, "nls": nls.value,
+           "texts": [texts[i].decode("utf-8") for i in range(nt.value)] if texts else None}
+    if labels:
+        groups = 1 if same.value else nt.value
+        out["labels"] = [[labels[g][j].decode("utf-8") for j in range(nl[0 if same.value else g])] for g in range(groups)]
+        out["num_labels"] = [nl[i] for i in range(nt.value)]
+    else:
+        out["labels"] = None
+    return out
+
+
+def test_parse_json_same_semantics_as_reference(tk_json):
+    from gliclass.c_amd import _lib
+    model = _lib.model()
+    doc = {"texts": ["One day I will see the world!", "Δοκιμή \"quoted\" \\ back\nslash é \U0001f600"],
+           "labels": [["travel", "dreams", "sport"], ["ignored"]], "same_labels": True, "classification_type": "multi-label"}
+    r = _parse(model, json.dumps(doc))                      # ensure_ascii: exercises \uXXXX and surrogate pairs
+    assert r["texts"] == doc["texts"] and r["same"] is True and r["type"] == "multi-label"
+    assert r["labels"] == [["travel", "dreams", "sport"]] and r["num_labels"] == [3, 3] and r["nls"] == 3   # only labels[0] (read_data.c:85-107)
+    r = _parse(model, json.dumps(doc, ensure_ascii=False))
+    assert r["texts"] == doc["texts"]
+    doc2 = dict(doc, same_labels=False, labels=[["a"], ["b", "c", "d"]], classification_type="single-label")
+    r = _parse(model, json.dumps(doc2))
+    assert r["labels"] == [["a"], ["b", "c", "d"]] and r["num_labels"] == [1, 3] and r["type"] == "single-label" and r["same"] is False
+    # label-group count must match the text count (read_data.c:113-117): labels stay unset
+    r = _parse(model, json.dumps(dict(doc2, labels=[["a"]])))
+    assert r["labels"] is None and r["num_texts"] == 2
+    # missing fields leave the caller's defaults untouched; malformed input leaves everything untouched
+    r = _parse(model, json.dumps({"texts": ["x"]}))
+    assert r["type"] is None and r["labels"] is None and r["same"] is False
+    r = _parse(model, '{"texts": ["x"], ')
+    assert r["num_texts"] == 0 and r["texts"] is None
+    assert model.string_to_bool(b"true") and model.string_to_bool(b"1") and not model.string_to_bool(b"false") and not model.string_to_bool(b"0")

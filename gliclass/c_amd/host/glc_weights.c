@@ -259,7 +259,13 @@ static int load_blob(const char* path, glc_weights* w) {
 int glc_weights_load(const char* path, glc_weights* out) {
     if (!path || !out) return -1;
     memset(out, 0, sizeof(*out));
-    int rc = strncmp(path, "synthetic:", 10) == 0 ? load_synthetic(path, out) : load_blob(path, out);
+    int rc;
+    struct stat sb;
+    const size_t pl = strlen(path);
+    if (strncmp(path, "synthetic:", 10) == 0) rc = load_synthetic(path, out);
+    else if ((stat(path, &sb) == 0 && S_ISDIR(sb.st_mode)) || (pl > 12 && !strcmp(path + pl - 12, ".safetensors")))
+        rc = glc_load_hf_checkpoint(path, out);                 /* HF directory (config.json + model.safetensors) */
+    else rc = load_blob(path, out);
     if (rc != 0) glc_weights_free(out);
     return rc;
 }

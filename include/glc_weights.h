@@ -19,8 +19,11 @@ typedef struct glc_weights {
     float* _owned;          /* synthetic: one allocation holding every tensor */
 } glc_weights;
 
-/* path = file or "synthetic:<name>[:seed]". Returns 0 / -1 (message on stderr). */
+/* path = .glcw blob | "synthetic:<name>[:seed]" | HF checkpoint (a directory with config.json + model.safetensors, or
+ * the .safetensors file itself).  Returns 0 / -1 (message on stderr). */
 int glc_weights_load(const char* path, glc_weights* out);
+/* The HF-checkpoint branch of glc_weights_load (host/glc_safetensors.c). `out` must be zeroed. */
+int glc_load_hf_checkpoint(const char* path, glc_weights* out);
 void glc_weights_free(glc_weights* w);
 
 uint64_t glc_fnv1a64(const char* s);

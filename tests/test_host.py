@@ -311,3 +311,73 @@ def test_length_bucket_planner():
     assert len(plan([1024, 900, 800, 700, 650, 600, 550, 520], 4)[1]) == 2
     assert len(plan([777] * 40, 4)[1]) == 2
     assert len(plan(big, 1)[1]) == 2
+
+
+def _hf_config_json(cfg, **over):
+    """config.json in the layout of a GLiClass checkpoint: backbone config under `encoder_config`, head fields on top."""
+    if cfg.backbone == 0:
+        enc = {"model_type": "deberta-v2", "hidden_size": cfg.hidden, "num_hidden_layers": cfg.layers, "num_attention_heads": cfg.heads,
+               "intermediate_size": cfg.inter, "vocab_size": cfg.vocab - 2, "relative_attention": True, "position_buckets": cfg.pos_buckets,
+               "max_relative_positions": -1, "max_position_embeddings": cfg.max_rel_pos, "norm_rel_ebd": "layer_norm", "share_att_key": True,
+               "pos_att_type": ["p2c", "c2p"], "position_biased_input": False, "type_vocab_size": 0, "layer_norm_eps": cfg.ln_eps, "pad_token_id": 0}
+    else:
+        enc = {"model_type": "qwen2", "hidden_size": cfg.hidden, "num_hidden_layers": cfg.layers, "num_attention_heads": cfg.heads,
+               "num_key_value_heads": cfg.kv_heads, "intermediate_size": cfg.inter, "vocab_size": cfg.vocab - 2, "rms_norm_eps": cfg.ln_eps,
+               "rope_theta": cfg.rope_theta}
+    top = {"model_type": "GLiClass", "architecture_type": "uni-encoder", "encoder_config": enc, "class_token_index": cfg.class_token_index,
+           "text_token_index": cfg.text_token_index, "pooling_strategy": {0: "first", 1: "avg", 2: "last"}[cfg.pooling], "scorer_type": "simple",
+           "embed_class_token": True, "normalize_features": False, "use_lstm": False, "vocab_size": cfg.vocab}
+    top.update(over)
+    return top
+
+
+def test_native_hf_checkpoint_import(libs, tmp_path):
+    """SURVEY.md §8f-2 natively: config.json + model.safetensors (F32 / F16 / BF16, GLiClass-style prefixes) -> glc_weights_load;
+    the tensors and the derived configuration equal the python importer's; unsupported configurations are refused."""
+    import json
+    torch = pytest.importorskip("torch")
+    st = pytest.importorskip("safetensors.torch")
+    _lib, hip, model = libs
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    for cname, prefix in (("tiny", "encoder_model.model."), ("dec-tiny", "decoder_model.model.")):
+        cfg = CONFIGS[cname]
+        ref = weights.make_weights(cfg, 11)
+        names = [s[0] for s in weights.tensor_specs(cfg)]
+        for dt in (torch.float32, torch.float16, torch.bfloat16):
+            d = tmp_path / f"{cname}_{str(dt).split('.')[-1]}"
+            d.mkdir()
+            sd = {(prefix if "projector" not in n else "") + n: torch.from_numpy(ref[n]).to(dt) for n in names}
+            sd["some.unrelated.buffer"] = torch.zeros(3, dtype=torch.int64)
+            st.save_file(sd, str(d / "model.safetensors"), metadata={"format": "pt"})
+            (d / "config.json").write_text(json.dumps(_hf_config_json(cfg)))
+            for src in (str(d), str(d / "model.safetensors")):
+                W = _lib.Weights()
+                assert model.glc_weights_load(src.encode(), C.byref(W)) == 0, src
+                for f in ("vocab", "hidden", "layers", "heads", "head_dim", "inter", "pos_buckets", "max_rel_pos", "pad_id", "cls_id", "sep_id",
+                          "class_token_index", "text_token_index", "pooling", "scorer", "embed_class_token", "normalize_features", "backbone",
+                          "kv_heads", "causal"):
+                    if cfg.backbone == 1 and f in ("pos_buckets", "max_rel_pos"):
+                        continue
+                    assert getattr(W.cfg, f) == getattr(cfg, f), (cname, f)
+                assert abs(W.cfg.ln_eps - cfg.ln_eps) < 1e-12 and W.n_tensors == len(names)
+                for i, n in enumerate(names):
+                    got = np.ctypeslib.as_array(W.tensors[i], shape=(ref[n].size,))
+                    want = torch.from_numpy(ref[n]).to(dt).float().numpy().ravel()
+                    assert np.array_equal(got, want), (n, dt)
+                model.glc_weights_free(C.byref(W))
+    # refusals (message on stderr, -1)
+    cfg = CONFIGS["tiny"]
+    d = tmp_path / "tiny_float32"
+    for over in ({"scorer_type": "mlp"}, {"architecture_type": "bi-encoder"}, {"use_lstm": True}, {"pooling_strategy": "max"}):
+        (d / "config.json").write_text(json.dumps(_hf_config_json(cfg, **over)))
+        W = _lib.Weights()
+        assert model.glc_weights_load(str(d).encode(), C.byref(W)) != 0, over
+    bad = _hf_config_json(cfg)
+    bad["encoder_config"]["share_att_key"] = False
+    (d / "config.json").write_text(json.dumps(bad))
+    W = _lib.Weights()
+    assert model.glc_weights_load(str(d).encode(), C.byref(W)) != 0
+    (d / "config.json").write_text(json.dumps(_hf_config_json(cfg)))
+    os.remove(d / "model.safetensors")
+    assert model.glc_weights_load(str(d).encode(), C.byref(W)) != 0

@@ -8,6 +8,8 @@
  *   parallel_preprocess               (main.c:116-118)   prompt builder + tokenizer + tensors, OpenMP over batches
  *   inference loop                    (main.c:141-150)   parallel_inference: batches dealt to the session's GPUs
  *   parallel_postprocess              (main.c:153-155)   sigmoid / threshold / argmax, batch-atomic printing
+ *     (default: the three stages pipelined per batch by parallel_classify, output in batch order; GLICLASS_PIPELINE=0 runs
+ *      them as the reference's three phases)
  *   release                           (main.c:173-187)
  *
  * usage: gliclass_main /path/to/data.json <prompt_first: true|false> [tokenizer.json] [model.glcw | synthetic:cfg[:seed]]
@@ -89,12 +91,18 @@ int main(int argc, char* argv[]) {
     OrtValue** attention_mask_tensors = (OrtValue**)calloc(num_batches ? num_batches : 1, sizeof(OrtValue*));
     OrtValue** output_tensors = (OrtValue**)calloc(num_batches ? num_batches : 1, sizeof(OrtValue*));
 
+    const char* pl = getenv("GLICLASS_PIPELINE");
     double start_time = omp_get_wtime();
-    parallel_preprocess(texts, labels, num_labels, num_texts, same_labels, prompt_first, tokenizer_handler,
-                        input_ids_tensors, attention_mask_tensors);
-    parallel_inference(session, input_ids_tensors, attention_mask_tensors, num_batches, output_tensors);
-    parallel_postprocess(output_tensors, num_batches, num_texts, texts, labels, num_labels, same_labels, num_labels_size,
-                         classification_type);
+    if (pl && pl[0] == '0') {                     /* the reference's three phases, a barrier after each (main.c:116-155) */
+        parallel_preprocess(texts, labels, num_labels, num_texts, same_labels, prompt_first, tokenizer_handler,
+                            input_ids_tensors, attention_mask_tensors);
+        parallel_inference(session, input_ids_tensors, attention_mask_tensors, num_batches, output_tensors);
+        parallel_postprocess(output_tensors, num_batches, num_texts, texts, labels, num_labels, same_labels, num_labels_size,
+                             classification_type);
+    } else {                                      /* default: the same stages pipelined per batch, results printed in batch order */
+        parallel_classify(session, tokenizer_handler, texts, labels, num_labels, num_texts, same_labels, num_labels_size,
+                          prompt_first, classification_type);
+    }
     double end_time = omp_get_wtime();
     printf("Execution time: %f seconds\n", end_time - start_time);
 

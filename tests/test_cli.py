@@ -61,8 +61,9 @@ def _prompts(labels_for, prompt_first):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("same,prompt_first,ctype", [(True, True, "multi-label"), (False, False, "multi-label"), (True, False, "single-label")])
-def test_launcher_end_to_end_vs_oracle(workdir, same, prompt_first, ctype):
+@pytest.mark.parametrize("same,prompt_first,ctype,pipeline", [(True, True, "multi-label", "1"), (False, False, "multi-label", "0"),
+                                                                (True, False, "single-label", "1"), (False, True, "multi-label", "1")])
+def test_launcher_end_to_end_vs_oracle(workdir, same, prompt_first, ctype, pipeline):
     import oracle_c
     from gliclass.c_amd import weights
     from gliclass.c_amd.config import CONFIGS
@@ -73,7 +74,7 @@ def test_launcher_end_to_end_vs_oracle(workdir, same, prompt_first, ctype):
     weights.write_blob(blob, cfg, w)
     data, labels = _write_data(workdir, same, ctype, f"data_{int(same)}{int(prompt_first)}.json")
     labels_for = (lambda i: labels[0]) if same else (lambda i: labels[i])
-    env = dict(os.environ, GLICLASS_DTYPE="f32", GLICLASS_THRESHOLD="0.0")
+    env = dict(os.environ, GLICLASS_DTYPE="f32", GLICLASS_THRESHOLD="0.0", GLICLASS_PIPELINE=pipeline)
     r = subprocess.run([EXE, data, "true" if prompt_first else "false", str(workdir / "tok.json"), blob], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     for stage in ("parse_json", "create_tokenizer", "initialize_ort_api", "initialize_ort_environment", "create_ort_session"):
@@ -109,3 +110,31 @@ def test_launcher_end_to_end_vs_oracle(workdir, same, prompt_first, ctype):
         flat_got = sorted(s for v in got.values() for _, s in v)
         flat_want = sorted(max(v.values()) for v in want.values())
         assert np.abs(np.array(flat_got) - np.array(flat_want)).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_pipelined_stages_print_the_same_blocks_in_batch_order(workdir):
+    """parallel_classify (pre / inference / post pipelined per batch) against the reference's three phases
+    (GLICLASS_PIPELINE=0): the same per-text output blocks; the pipelined run prints them in batch order."""
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    cfg = dataclasses.replace(CONFIGS["tiny"], name="tiny-tok", vocab=6003, class_token_index=6001, text_token_index=6002)
+    blob = str(workdir / "tiny_tok_p.glcw")
+    weights.write_blob(blob, cfg, weights.make_weights(cfg, 3))
+    texts = [f"{i}: " + TEXTS[i % len(TEXTS)] + " extra words" * (i % 7) for i in range(53)]          # 14 batches of 4, last one short
+    (workdir / "many.json").write_text(json.dumps({"texts": texts, "labels": [LABELS], "same_labels": True, "classification_type": "multi-label"}))
+
+    def run(pipeline, threads):
+        env = dict(os.environ, GLICLASS_DTYPE="f32", GLICLASS_THRESHOLD="0.3", GLICLASS_PIPELINE=pipeline, GLICLASS_BATCH_SIZE="4",
+                   GLICLASS_PIPELINE_THREADS=threads)
+        r = subprocess.run([EXE, str(workdir / "many.json"), "true", str(workdir / "tok.json"), blob], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        body = r.stdout.split("DONE: create_ort_session;\n\n", 1)[1].rsplit("Execution time:", 1)[0]
+        return [blk for blk in body.split("\n\n") if blk.strip()]
+
+    three_phase = run("0", "1")
+    for threads in ("1", "3", "8"):
+        piped = run("1", threads)
+        assert sorted(piped) == sorted(three_phase) and len(piped) == len(texts)
+        order = [int(re.match(r"Text_\d+: (\d+): ", blk).group(1)) for blk in piped]
+        assert order == list(range(len(texts)))                                        # deterministic: batch order, then row order

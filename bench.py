@@ -70,7 +70,7 @@ def cpu_baseline(cfg, wptrs, n_t, S, C_labels, seqs):
     import oracle_c
     from gliclass.c_amd import synth
     ids, mask, _ = synth.make_inputs(cfg, seqs, S, C_labels, seed=1234)
-    lib = oracle_c.lib()
+    lib = oracle_c.lib()              # team sized to the CPUs this job may really use (affinity / cgroup quota): `cores` below
     logits = np.zeros((seqs, C_labels), np.float32)
     c_out = C.c_int(0)
     cc = oracle_c._cfg(cfg)

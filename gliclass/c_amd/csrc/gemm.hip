@@ -14,6 +14,7 @@
 // flips the operands (lane = n, regs = 4 consecutive m) to write V transposed.  Q, K and V^T leave
 // this kernel in the fragment-major layouts of glc_layout.h (what the attention MFMAs load).
 #include <stdlib.h>
+#include <string.h>
 #include <atomic>
 #include "glc_common.h"
 #include "glc_kernels.h"
@@ -25,8 +26,16 @@ constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 128;          // bytes of K per row per stage
 constexpr int ROWP = ROWB + 16;    // padded LDS row stride (bytes)
 
-template <typename T, int EPI, bool SPLITK = false>
+// SPLIT (T = float only): the fp32 operands are split on their way into LDS into two f16 halves, x = hi + lo with hi = f16(x),
+// lo = f16(x - hi), and every product runs as three f16 MFMAs a_lo*w_hi + a_hi*w_lo + a_hi*w_hi with fp32 accumulation
+// (the lo*lo term is below 2^-22 of the product).  That keeps ~21-22 mantissa bits of each operand — the parity-grade
+// accuracy of the fp32 mode (tests assert the same 1e-4 envelope) — at 16 cycles x 3 per 16x16x32 block instead of
+// 32 cycles x 8 on the fp32 16x16x4 MFMA, i.e. up to 5.3x the fp32 matrix rate.  Range: operands must stay below the f16
+// maximum (65504); the engine checks nothing at run time, GLICLASS_F32_GEMM=native selects the plain fp32-MFMA kernel.
+// LDS image per row and stage (32 k): [32 hi halves | 32 lo halves] = the same 128 bytes as 32 floats.
+template <typename T, int EPI, bool SPLITK = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
+    static_assert(!SPLIT || sizeof(T) == 4, "the split path takes fp32 operands");
     typedef typename Frag<T>::type frag_t;
     constexpr int BK = ROWB / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * ROWP];
@@ -70,11 +79,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
             rw[i] = *reinterpret_cast<const u32x4*>(gw + (size_t)i * gstep + (size_t)kt * BK);
         }
     };
+    typedef __attribute__((ext_vector_type(4))) f16_t f16x4_t;
+    auto split_store = [&](unsigned char* row, const u32x4& raw) {     // 4 floats (k = 4cc..4cc+3) -> hi at cc*8, lo at 64 + cc*8
+        const f32x4 xf = __builtin_bit_cast(f32x4, raw);    // (bit_cast of a single vector ELEMENT reads element 0 under hipcc 7.2)
+        f16x4_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f16_t h = (f16_t)xf[e];
+            hi[e] = h;
+            lo[e] = (f16_t)(xf[e] - (float)h);
+        }
+        *reinterpret_cast<f16x4_t*>(row + cc * 8) = hi;
+        *reinterpret_cast<f16x4_t*>(row + 64 + cc * 8) = lo;
+    };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(As + (size_t)buf * BM * ROWP + (srow + 32 * i) * ROWP + cc * 16) = ra[i];
-            *reinterpret_cast<u32x4*>(Bs + (size_t)buf * BN * ROWP + (srow + 32 * i) * ROWP + cc * 16) = rw[i];
+            unsigned char* arow = As + (size_t)buf * BM * ROWP + (srow + 32 * i) * ROWP;
+            unsigned char* brow = Bs + (size_t)buf * BN * ROWP + (srow + 32 * i) * ROWP;
+            if constexpr (SPLIT) {
+                split_store(arow, ra[i]);
+                split_store(brow, rw[i]);
+            } else {
+                *reinterpret_cast<u32x4*>(arow + cc * 16) = ra[i];
+                *reinterpret_cast<u32x4*>(brow + cc * 16) = rw[i];
+            }
         }
     };
 
@@ -85,6 +114,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
         if (kt + 1 < nk) gload(kt + 1);
         const unsigned char* as = As + (size_t)cur * BM * ROWP + (wm * 64 + r16) * ROWP + g * 16;
         const unsigned char* bs = Bs + (size_t)cur * BN * ROWP + (wn * 64 + r16) * ROWP + g * 16;
+        if constexpr (SPLIT) {
+            f16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(as + i * 16 * ROWP);
+                al[i] = *reinterpret_cast<const f16x8*>(as + i * 16 * ROWP + 64);
+                bh[i] = *reinterpret_cast<const f16x8*>(bs + i * 16 * ROWP);
+                bl[i] = *reinterpret_cast<const f16x8*>(bs + i * 16 * ROWP + 64);
+            }
+            if (!vmode) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {                                  // D[n][m]; small terms first
+                        mma16(bh[j], al[i], acc[j][i]);
+                        mma16(bl[j], ah[i], acc[j][i]);
+                        mma16(bh[j], ah[i], acc[j][i]);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                                  // D[m][n]
+                        mma16(al[i], bh[j], acc[i][j]);
+                        mma16(ah[i], bl[j], acc[i][j]);
+                        mma16(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             frag_t af[4], bf[4];
@@ -104,6 +162,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mma16(af[i], bf[j], acc[i][j]);   // D[m][n]
             }
+        }
         }
         if (kt + 1 < nk) sstore(cur ^ 1);
         __syncthreads();
@@ -223,7 +282,7 @@ int splitk_parts(int epi, const GemmArgs& a, int nk) {
     return parts < 2 ? 1 : parts;
 }
 
-template <typename T> void launch_t(hipStream_t st, int epi, const GemmArgs& a) {
+template <typename T, bool SPLIT = false> void launch_t(hipStream_t st, int epi, const GemmArgs& a) {
     const int nskip = (epi == EPI_QKV && a.qkv_skip_q) ? a.H / BN : 0;   // pruned last layer: K and V^T columns only
     dim3 grid(a.N / BN - nskip, a.Mpad / BM), block(256);
     const int parts = splitk_parts(epi, a, a.K / (ROWB / (int)sizeof(T)));
@@ -231,20 +290,20 @@ template <typename T> void launch_t(hipStream_t st, int epi, const GemmArgs& a) 
         grid.z = parts;
         const unsigned rblocks = (unsigned)(((size_t)a.Mpad * (a.N / 4) + 255) / 256);
         switch (epi) {
-            case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, true>), grid, block, 0, st, a, parts);
+            case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, true, SPLIT>), grid, block, 0, st, a, parts);
                            hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI_BIAS>), dim3(rblocks), block, 0, st, a, parts); break;
-            case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU, true>), grid, block, 0, st, a, parts);
+            case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU, true, SPLIT>), grid, block, 0, st, a, parts);
                            hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI_GELU>), dim3(rblocks), block, 0, st, a, parts); break;
-            default:       hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID, true>), grid, block, 0, st, a, parts);
+            default:       hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID, true, SPLIT>), grid, block, 0, st, a, parts);
                            hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI_RESID>), dim3(rblocks), block, 0, st, a, parts); break;
         }
         return;
     }
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS>), grid, block, 0, st, a, 1); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU>), grid, block, 0, st, a, 1); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID>), grid, block, 0, st, a, 1); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_QKV>), grid, block, 0, st, a, 1); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_BIAS, false, SPLIT>), grid, block, 0, st, a, 1); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_GELU, false, SPLIT>), grid, block, 0, st, a, 1); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_RESID, false, SPLIT>), grid, block, 0, st, a, 1); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_nt_kernel<T, EPI_QKV, false, SPLIT>), grid, block, 0, st, a, 1); break;
     }
 }
 
@@ -266,7 +325,12 @@ const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& 
     if (epi == EPI_RESID && !a.resid) return "gemm: null residual";
     if (a.W2 && (a.m_split % BM || a.m_split <= 0 || a.m_split >= a.Mpad)) return "gemm: m_split must be a tile-aligned row inside the matrix";
     switch (dtype) {
-        case GLC_DT_F32: launch_t<float>(st, epi, a); break;
+        case GLC_DT_F32: {
+            // default: split-f16 (3-MFMA) products; GLICLASS_F32_GEMM=native keeps the fp32 16x16x4 MFMA kernel (A/B and wide-range data)
+            static const bool split = !(getenv("GLICLASS_F32_GEMM") && !strcmp(getenv("GLICLASS_F32_GEMM"), "native"));
+            if (split) launch_t<float, true>(st, epi, a); else launch_t<float>(st, epi, a);
+            break;
+        }
         case GLC_DT_BF16: launch_t<bf16_t>(st, epi, a); break;
         case GLC_DT_F16: launch_t<f16_t>(st, epi, a); break;
         default: return "gemm: bad dtype";

@@ -12,6 +12,7 @@
 #include <omp.h>
 #include <stdlib.h>
 
+#include "glc_cpus.h"
 #include "model.h"
 #include "postprocessor.h"
 #include "preprocessor.h"
@@ -34,7 +35,7 @@ void parallel_preprocess(char** texts, char*** labels, size_t* num_labels, size_
         fprintf(stderr, "Error: parallel_preprocess: NULL tokenizer handle\n");
         return;
     }
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(glc_host_cpus())
     for (size_t i = 0; i < num_texts; i += bs) {
         const size_t n = (i + bs > num_texts) ? (num_texts - i) : bs;
         const char** batch_texts = (const char**)&texts[i];
@@ -55,7 +56,7 @@ void parallel_postprocess(OrtValue** output_tensors, size_t num_batches, size_t 
     const size_t bs = env_size("GLICLASS_BATCH_SIZE", BATCH_SIZE);
     const char* ts = getenv("GLICLASS_THRESHOLD");
     const float threshold = (ts && *ts) ? strtof(ts, NULL) : THRESHOLD;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(glc_host_cpus())
     for (size_t i = 0; i < num_batches; ++i) {
         const size_t n = (i == num_batches - 1) ? (num_texts - i * bs) : bs;
         const char** batch_texts = (const char**)&texts[i * bs];
@@ -93,7 +94,7 @@ size_t parallel_classify(OrtSession* session, TokenizerHandle tokenizer_handler,
     unsigned char* state = (unsigned char*)calloc(nb, 1);            /* 0 pending, 1 done, 2 failed */
     if (!outs || !state) { free(outs); free(state); fprintf(stderr, "Error: parallel_classify: out of memory\n"); return nb; }
     size_t next_print = 0, failed = 0;
-    int team = (int)env_size("GLICLASS_PIPELINE_THREADS", (size_t)omp_get_max_threads());
+    int team = (int)env_size("GLICLASS_PIPELINE_THREADS", (size_t)glc_host_cpus());
     if ((size_t)team > nb) team = (int)nb;
     if (team < 1) team = 1;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(team)

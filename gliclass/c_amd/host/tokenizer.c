@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "glc_cpus.h"
 #include "glc_json.h"
 #include "glc_unicode_tables.h"
 #include "tokenizers_c.h"
@@ -1017,7 +1018,7 @@ void tokenizers_encode(TokenizerHandle handle, const char* data, size_t len, int
 void tokenizers_encode_batch(TokenizerHandle handle, const char** data, size_t* len, size_t num_seqs, int add_special_token,
                              TokenizerEncodeResult* results) {
     const glc_tokenizer* tk = (const glc_tokenizer*)handle;
-#pragma omp parallel for schedule(dynamic, 1) if (num_seqs > 1)
+#pragma omp parallel for schedule(dynamic, 1) if (num_seqs > 1) num_threads(glc_host_cpus())
     for (size_t i = 0; i < num_seqs; ++i) {
         results[i].token_ids = NULL; results[i].len = 0;
         if (tk) encode_one(tk, data[i], len[i], add_special_token, &results[i]);

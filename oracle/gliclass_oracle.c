@@ -468,6 +468,15 @@ int glo_forward_decoder(const glo_config* cfg, const float* const* tensors, cons
 /* /root/reference/src/postprocessor.c:14-16 */
 float glo_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+/* Caps the OpenMP team (oracle_c.py passes the CPUs this process may really use: affinity and cgroup quota). */
+void glo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int glo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

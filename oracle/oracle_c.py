@@ -33,10 +33,42 @@ def build(force=False):
 _lib = None
 
 
+def effective_cpus():
+    """CPUs this process can really use: min(affinity mask, cgroup CPU quota, online CPUs).  A GPU box shows all of its 128
+    cores but gives a job a share of them; a 128-thread OpenMP team spinning at its barriers inside a CFS quota makes the oracle
+    crawl (minutes instead of seconds), so the team is sized to the share."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0 and period > 0:
+                    n = min(n, max(1, -(-quota // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("GLO_THREADS") or os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # honoured if libgomp is first initialised by this load
         _lib = C.CDLL(build())
+        _lib.glo_set_threads.argtypes = [C.c_int]
+        _lib.glo_set_threads(min(effective_cpus(), 64))
         _lib.glo_forward.restype = C.c_int
         _lib.glo_forward.argtypes = [C.POINTER(GloConfig), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]

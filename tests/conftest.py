@@ -10,6 +10,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# OpenMP teams (oracle, host layer, torch) sized to the CPUs this job may really use, and sleeping rather than spinning at
+# barriers: on a GPU box that shows 128 cores but grants a share of them, 128 spinning threads inside the CFS quota turned a
+# 2-second oracle call into minutes (set before any OpenMP runtime is loaded).
+import oracle_c  # noqa: E402
+os.environ.setdefault("OMP_NUM_THREADS", str(min(oracle_c.effective_cpus(), 64)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

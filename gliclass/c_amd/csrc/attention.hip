@@ -61,9 +61,15 @@ template <bool ON> struct SegClock {
 
 // fp32 (T = float, the parity-grade mode) runs the same code on 32x32x2 fp32 MFMAs; its fragments are twice as large, so it is
 // built for one wave per SIMD (512 VGPRs) with the rolled band loop.
-template <typename T, bool UNROLL6 /* the lean two-step band loop (default for 16-bit T); false = rolled loop */, bool DIAG = false>
+// SPLIT (T = float): the operand units hold split-f16 pairs (glc_common.h f16x8s) — same addresses, same code, every product is
+// three f16 32x32x16 MFMAs (3 x 32 cycles) instead of eight fp32 32x32x2 MFMAs (8 x 64 cycles); the probabilities are split on
+// the fly before P*V.  Error class of the fp32 kernel (tests: same 1e-4 bound), operands must be inside the f16 range.
+template <bool SPLIT, typename T> struct BandFrag { typedef typename AFrag<T>::type type; };
+template <typename T> struct BandFrag<true, T> { typedef f16x8s type; };
+template <typename T, bool UNROLL6 /* the lean two-step band loop (default for 16-bit T); false = rolled loop */, bool DIAG = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(AttnArgs a) {
-    typedef typename AFrag<T>::type frag_t;
+    static_assert(!SPLIT || sizeof(T) == 4, "split operands live in the fp32 layouts");
+    typedef typename BandFrag<SPLIT, T>::type frag_t;
     constexpr int UNITB = 512 * (int)sizeof(T);      // bytes of one fragment unit (64 lanes x 8 elements)
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * LROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -187,8 +193,17 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             frag_t pfr;
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+                for (int j = 0; j < 8; ++j) {
+                    const f16_t ph = (f16_t)sv[8 * t + j];
+                    pfr.hi[j] = ph;
+                    pfr.lo[j] = (f16_t)(sv[8 * t + j] - (float)ph);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+            }
             mma32(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
             mma32(vt[1][t], pfr, o1);     //                   dd + 32
         }
@@ -500,6 +515,7 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
     if (impl == 2 && !a.otab) return "attention: the band kernel needs the offset table";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention: bad shape";
     if (impl == 2 && (a.sel_b || !a.Qh)) return "attention: the band kernel takes no row selection";
+    if (a.split && (impl != 2 || dtype != GLC_DT_F32)) return "attention: split operands exist for the fp32 band kernel only";
     if (impl == 2) {
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
@@ -507,7 +523,8 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
         static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: lean two-step band loop; the env picks the rolled one (A/B)
         if (dtype == GLC_DT_F32) {
             if (a.stamps) return "attention: the stamped build exists for f16 only";
-            hipLaunchKernelGGL((attn_band_kernel<float, false>), grid, block, dyn, st, a);
+            if (a.split) hipLaunchKernelGGL((attn_band_kernel<float, false, false, true>), grid, block, dyn, st, a);
+            else hipLaunchKernelGGL((attn_band_kernel<float, false>), grid, block, dyn, st, a);
         } else if (a.stamps) {
             if (dtype != GLC_DT_F16) return "attention: the stamped build exists for f16 only";
             hipLaunchKernelGGL((attn_band_kernel<f16_t, false, true>), grid, block, dyn, st, a);   // rolled loop: room for the stamp registers

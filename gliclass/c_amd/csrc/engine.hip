@@ -55,6 +55,7 @@ struct LayerW {
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;       // f32
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; // f32
     void *PK = nullptr, *PQ = nullptr;                                        // T [nh, P, 64]
+    void *PKs = nullptr, *PQs = nullptr;                                      // fp32 mode: the same tables as split-f16 units (band kernel, AttnArgs::split)
 };
 
 }  // namespace
@@ -63,6 +64,7 @@ struct glc_engine {
     glc_model_config cfg{};
     int dtype = GLC_F32, device = 0, attn_impl = 0;
     bool prune_last = true;         // last layer only on the rows the head reads (exact)
+    bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
@@ -386,16 +388,18 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
 
     const int impl = e->attn_impl ? e->attn_impl : 2;        // MFMA band kernel for every operand type (fp32: 32x32x2 MFMAs); 1 = straightforward kernel
+    const bool asplit = e->attn_split && impl == 2 && dt == GLC_F32;        // fp32 mode: split-f16 operand units for the band kernel
     const bool prune = e->prune_last && !e->keep_hidden && c.pooling == GLC_POOL_FIRST;
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
         const bool last = prune && l == c.layers - 1;
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
-        g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
+        g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit;
         if (last) break;
         { Prof p(e, PC_QKV); KCHK(launch_gemm_auto(e, dt, EPI_QKV, g), false); }
-        AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+        AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+        a.split = asplit;
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
@@ -425,13 +429,13 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         const bool band_sel = impl == 2;     // 16-bit: band kernel on the query tiles that hold selected rows; f32: row-selection kernel
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = band_sel ? 0 : 1;
-        g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H;
+        g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit && band_sel;
         KCHK(launch_gemm_auto(e, dt, EPI_QKV, g), false);
         if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)B * (Sp >> 5), st), false);
         KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         if (band_sel) {
-            AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-            a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp];
+            AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+            a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;
             KCHK(glc_launch_attention(st, dt, 2, a), false);
             KCHK(glc_launch_gather_sel(st, dt, e->CTX, e->sel_b, e->sel_q, e->CTXs, R, Sp, H), false);
         } else {
@@ -609,6 +613,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     e->cfg = *cfg; e->dtype = dtype; e->device = device;
     if (e->cfg.kv_heads <= 0) e->cfg.kv_heads = e->cfg.heads;
     if (const char* pv = getenv("GLICLASS_PRUNE_LAST")) e->prune_last = atoi(pv) != 0;
+    { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
         if (!create_decoder(e, tensors)) { glc_engine_destroy(e); return nullptr; }
@@ -682,6 +687,14 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             g.Mpad = Ppad; g.N = 3 * H; g.K = H; g.Mvalid = P; g.Sp = P; g.nh = nh; g.H = H;
             const char* gm = glc_launch_gemm_auto(e->stream, dtype, EPI_QKV, g);
             if (gm) { set_err(gm); lok = false; }
+            if (lok && e->attn_split) {      // the same tables once more as split-f16 units for the fp32 band kernel
+                w.PKs = dmalloc(e, (size_t)nh * P * 64 * es);
+                w.PQs = dmalloc(e, (size_t)nh * P * 64 * es);
+                if (!w.PKs || !w.PQs) { lok = false; break; }
+                g.Qh = w.PQs; g.Kh = w.PKs; g.qkv_split = 1;
+                gm = glc_launch_gemm_auto(e->stream, dtype, EPI_QKV, g);
+                if (gm) { set_err(gm); lok = false; }
+            }
         }
         if (!lok) { fail(); break; }
         const float* const* ht = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * L;

@@ -22,6 +22,17 @@
 
 namespace {
 
+// Split-f16 unit store (GemmArgs::qkv_split): `dst` addresses 4 consecutive elements (e & 7 in {0, 4}) of an 8-element fp32 unit;
+// the unit's 32 bytes become [8 hi halves | 8 lo halves] (glc_common.h f16x8s), so the 4 values go to halves (e&7).. of both parts.
+template <typename T> __device__ __forceinline__ void store4_split(T* dst, float a, float b, float c, float d) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(dst);
+    f16_t* unit = reinterpret_cast<f16_t*>(addr & ~(uintptr_t)31);
+    const int sub = (int)((addr & 31) >> 2);                               // 0 or 4
+    const f16_t ha = (f16_t)a, hb = (f16_t)b, hc = (f16_t)c, hd = (f16_t)d;
+    store4<f16_t>(unit + sub, (float)ha, (float)hb, (float)hc, (float)hd);
+    store4<f16_t>(unit + 8 + sub, a - (float)ha, b - (float)hb, c - (float)hc, d - (float)hd);
+}
+
 constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 128;          // bytes of K per row per stage
 constexpr int ROWP = ROWB + 16;    // padded LDS row stride (bytes)
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
                         const int bh = b * p.nh + hh;
                         T* dst = which == 0 ? reinterpret_cast<T*>(p.Qh) + glc_qoff(p.Sp, bh, s, dd)
                                             : reinterpret_cast<T*>(p.Kh) + glc_koff(p.Sp, bh, s, dd);
-                        store4<T>(dst, v0, v1, v2, v3);
+                        if (sizeof(T) == 4 && p.qkv_split) store4_split(dst, v0, v1, v2, v3);
+                        else store4<T>(dst, v0, v1, v2, v3);
                     }
                 } else {
                     store4<T>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n, v0, v1, v2, v3);
@@ -232,7 +244,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
                     int b = qkv_b0, s = m - qkv_b0 * p.Sp;
                     if (s >= p.Sp) { s -= p.Sp; ++b; }
                     T* dst = reinterpret_cast<T*>(p.Vt) + glc_voff(p.Sp, b * p.nh + hh, dd, s);
-                    store4<T>(dst, acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+                    if (sizeof(T) == 4 && p.qkv_split) store4_split(dst, acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+                    else store4<T>(dst, acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
                 }
             }
         }

@@ -62,6 +62,16 @@ __device__ __forceinline__ void mma32(const f32x8& a, const f32x8& b, f32x16& c)
     for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
 }
 
+// Split-f16 attention operand (fp32 mode): the 32 bytes a lane holds of an fp32 fragment unit carry [8 hi halves | 8 lo halves] of
+// the same 8 k-elements (x = hi + lo, hi = f16(x), lo = f16(x - hi)), so every address of the fp32 fragment-major layout stays
+// valid; a product is three f16 MFMAs a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with fp32 accumulation (lo*lo < 2^-22 of the product).
+struct f16x8s { f16x8 hi, lo; };
+__device__ __forceinline__ void mma32(const f16x8s& a, const f16x8s& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 

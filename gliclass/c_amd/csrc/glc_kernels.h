@@ -24,6 +24,7 @@ struct GemmArgs {
     unsigned long long* stamps = nullptr;   // gemm256 diagnostic build only: per (block<64, wave) cycle sums [compute, dma_wait, barrier_wait, total]
     int spread_dma = 0;                     // gemm256: issue the next stage's DMA between MFMA groups instead of up front
     int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
+    int qkv_split = 0;                      // QKV, T = float: write Q / K / V^T units as [8 hi halves | 8 lo halves] (split-f16 attention, glc_common.h f16x8s)
     // gemm_nt (128-tile) split-K for small M: the K loop is cut into `ksplit` parts (grid.z), each writes its fp32 partial tile to
     // ws[z][Mpad][N]; a second pass sums the parts in a fixed order and applies the epilogue.  ws_bytes = capacity of ws.
     float* ws = nullptr; size_t ws_bytes = 0;
@@ -80,6 +81,7 @@ struct AttnArgs {
     const int2* otab = nullptr;                       // band kernel: [2*Sp-1+128] byte offsets of row delta(q-k) in PQ (x) / PK (y), 64 clamped entries each side
     unsigned long long* stamps = nullptr;
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
+    int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);

@@ -244,6 +244,32 @@ def main():
             out["roofline"] = roof
         if cpu:
             out["cpu_baseline"] = cpu
+        if cpu and world == 1 and args.dtype != "f32":
+            # The same workload in the parity-grade mode (fp32 data, split-f16 three-MFMA products): the 16-bit
+            # throughput modes sit above the 1e-3 bar on these random-weight models, this one sits far below it.  Reported beside
+            # the headline number, never instead of it.
+            h32 = hipl.glc_engine_create(C.byref(W.cfg), C.cast(W.tensors, C.POINTER(C.c_void_p)), W.n_tensors, local_rank, DTYPES["f32"])
+            if h32:
+                p_ids = hipl.glc_device_malloc(h32, ids.nbytes); p_mask = hipl.glc_device_malloc(h32, mask.nbytes)
+                p_log = hipl.glc_device_malloc(h32, B * Cn * 4)
+                hipl.glc_memcpy_h2d(h32, p_ids, ids.ctypes.data, ids.nbytes)
+                hipl.glc_memcpy_h2d(h32, p_mask, mask.ctypes.data, mask.nbytes)
+                nsteps = max(2, min(args.steps, 5))
+                hipl.glc_engine_forward_device(h32, p_ids, p_mask, B, S, Cn, p_log)
+                hipl.glc_engine_sync(h32)
+                hipl.glc_timer_start(h32)
+                for _ in range(nsteps):
+                    hipl.glc_engine_forward_device(h32, p_ids, p_mask, B, S, Cn, p_log)
+                pms = float(hipl.glc_timer_stop_ms(h32)) / nsteps
+                got = np.zeros((args.cpu_seqs, Cn), np.float32)
+                c_out = C.c_int(0)
+                hipl.glc_engine_forward(h32, rids.ctypes.data, rmask.ctypes.data, args.cpu_seqs, S, got.ctypes.data, Cn, C.byref(c_out))
+                pe = np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref_logits.astype(np.float64)))).max()
+                out["parity_grade_mode"] = {"dtype": "f32 data, split-f16 x3 MFMA products", "value": round(B / (pms * 1e-3), 2),
+                                            "unit": "sequences/s", "ms_per_step": round(pms, 3), "steps": nsteps,
+                                            "gpu_vs_cpu_max_prob_err": float(pe), "bar": 1e-3}
+                hipl.glc_device_free(h32, p_ids); hipl.glc_device_free(h32, p_mask); hipl.glc_device_free(h32, p_log)
+                hipl.glc_engine_destroy(h32)
     sync()
     hipl.glc_device_free(h, d_ids); hipl.glc_device_free(h, d_mask); hipl.glc_device_free(h, d_logits)
     hipl.glc_engine_destroy(h)

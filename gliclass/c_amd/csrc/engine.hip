@@ -64,6 +64,7 @@ struct glc_engine {
     glc_model_config cfg{};
     int dtype = GLC_F32, device = 0, attn_impl = 0;
     bool prune_last = true;         // last layer only on the rows the head reads (exact)
+    bool w_presplit = false;        // weights of the split-f16 fp32 GEMMs are split once at load (encoder layers in fp32 mode; head projectors in every mode)
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
@@ -284,12 +285,17 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
 }
 
 // GEMM launches of the forward carry the engine's split-K workspace (used only when a shape has too few tiles, gemm.hip)
+static bool presplit_weight(const glc_engine* e, int dt, const void* W) {
+    if (!e->w_presplit || dt != GLC_F32) return false;
+    if (W == e->headw[0] || W == e->headw[2]) return true;                       // head projectors (their second group W2 goes with them)
+    return e->cfg.backbone != GLC_BACKBONE_DECODER;                              // encoder layer weights of the fp32 mode
+}
 const char* launch_gemm_auto(glc_engine* e, int dt, int epi, GemmArgs a) {
-    a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes;
+    a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes; a.w_presplit = presplit_weight(e, dt, a.W);
     return glc_launch_gemm_auto(e->stream, dt, epi, a);
 }
 const char* launch_gemm128(glc_engine* e, int dt, int epi, GemmArgs a) {
-    a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes;
+    a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes; a.w_presplit = presplit_weight(e, dt, a.W);
     return glc_launch_gemm(e->stream, dt, epi, a);
 }
 
@@ -541,7 +547,10 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
         if (!e->final_norm) break;
         const float* const* ht = tensors + 2 + GLC_DEC_TENSORS_PER_LAYER * L;
         bool hok = true;
-        for (int i = 0; i < 8 && hok; ++i) { e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr; }
+        for (int i = 0; i < 8 && hok; ++i) {
+            e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr;
+            if (hok && (i % 2 == 0) && e->w_presplit) { const char* pm = glc_launch_presplit(e->stream, e->headw[i], (size_t)H * H); if (pm) { set_err(pm); hok = false; } }
+        }
         if (!hok) break;
         if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err(std::string("engine_create: ") + hipGetErrorString(hipGetLastError())); break; }
         ok = true;
@@ -613,6 +622,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     e->cfg = *cfg; e->dtype = dtype; e->device = device;
     if (e->cfg.kv_heads <= 0) e->cfg.kv_heads = e->cfg.heads;
     if (const char* pv = getenv("GLICLASS_PRUNE_LAST")) e->prune_last = atoi(pv) != 0;
+    { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
@@ -681,10 +691,18 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             w.ln2g = upload_f32(e, t[14], H); w.ln2b = upload_f32(e, t[15], H);
             if (!w.bqkv || !w.bo || !w.ln1g || !w.ln1b || !w.b1 || !w.b2 || !w.ln2g || !w.ln2b) { lok = false; break; }
             if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // bqkv host buffer is reused
+            if (e->w_presplit && dtype == GLC_F32) {
+                const char* pm = glc_launch_presplit(e->stream, w.Wqkv, 3 * (size_t)H * H);
+                if (!pm) pm = glc_launch_presplit(e->stream, w.Wo, (size_t)H * H);
+                if (!pm) pm = glc_launch_presplit(e->stream, w.W1, (size_t)I * H);
+                if (!pm) pm = glc_launch_presplit(e->stream, w.W2, (size_t)H * I);
+                if (pm) { set_err(pm); lok = false; break; }
+            }
             // position projections (HF:296-302, share_att_key): PQ = query_proj(R)*log2e/sqrt(3d), PK = key_proj(R)
             GemmArgs g;
             g.A = Rt; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = w.PQ; g.Kh = w.PK; g.Vt = vscratch;
             g.Mpad = Ppad; g.N = 3 * H; g.K = H; g.Mvalid = P; g.Sp = P; g.nh = nh; g.H = H;
+            g.w_presplit = e->w_presplit && dtype == GLC_F32;
             const char* gm = glc_launch_gemm_auto(e->stream, dtype, EPI_QKV, g);
             if (gm) { set_err(gm); lok = false; }
             if (lok && e->attn_split) {      // the same tables once more as split-f16 units for the fp32 band kernel
@@ -699,7 +717,10 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         if (!lok) { fail(); break; }
         const float* const* ht = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * L;
         bool hok = true;
-        for (int i = 0; i < 8 && hok; ++i) { e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr; }
+        for (int i = 0; i < 8 && hok; ++i) {
+            e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr;
+            if (hok && (i % 2 == 0) && e->w_presplit) { const char* pm = glc_launch_presplit(e->stream, e->headw[i], (size_t)H * H); if (pm) { set_err(pm); hok = false; } }
+        }
         if (!hok) { fail(); break; }
         if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err(std::string("engine_create: ") + hipGetErrorString(hipGetLastError())); fail(); break; }
         (void)hipFree(staging);

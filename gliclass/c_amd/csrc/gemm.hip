@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
             unsigned char* brow = Bs + (size_t)buf * BN * ROWP + (srow + 32 * i) * ROWP;
             if constexpr (SPLIT) {
                 split_store(arow, ra[i]);
-                split_store(brow, rw[i]);
+                if (p.w_presplit) *reinterpret_cast<u32x4*>(brow + cc * 16) = rw[i];    // split once at load: the raw 128-byte group IS the row image
+                else split_store(brow, rw[i]);
             } else {
                 *reinterpret_cast<u32x4*>(arow + cc * 16) = ra[i];
                 *reinterpret_cast<u32x4*>(brow + cc * 16) = rw[i];

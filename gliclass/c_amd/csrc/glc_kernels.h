@@ -24,6 +24,7 @@ struct GemmArgs {
     unsigned long long* stamps = nullptr;   // gemm256 diagnostic build only: per (block<64, wave) cycle sums [compute, dma_wait, barrier_wait, total]
     int spread_dma = 0;                     // gemm256: issue the next stage's DMA between MFMA groups instead of up front
     int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
+    int w_presplit = 0;                     // gemm_nt split-f16 path (T = float): W already holds [32 hi halves | 32 lo halves] per 32-k group (glc_launch_presplit)
     int qkv_split = 0;                      // QKV, T = float: write Q / K / V^T units as [8 hi halves | 8 lo halves] (split-f16 attention, glc_common.h f16x8s)
     // gemm_nt (128-tile) split-K for small M: the K loop is cut into `ksplit` parts (grid.z), each writes its fp32 partial tile to
     // ws[z][Mpad][N]; a second pass sums the parts in a fixed order and applies the epilogue.  ws_bytes = capacity of ws.
@@ -138,5 +139,8 @@ const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void*
 
 // dtype conversion fp32 -> T (weights upload), n elements
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);
+// In place: every group of 32 consecutive floats becomes [32 hi halves | 32 lo halves] (x = hi + lo), the LDS row image of the
+// split-f16 GEMM (gemm.hip) — weights are split once at load instead of in every tile.  n % 32 == 0.
+const char* glc_launch_presplit(hipStream_t st, void* w, size_t n);
 // T [rows, H] -> fp32 (debug dumps)
 const char* glc_launch_to_f32(hipStream_t st, int dtype, const void* src, float* dst, size_t n);

@@ -337,6 +337,38 @@ const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* 
     return nullptr;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void presplit_kernel(float* __restrict__ w, size_t ngroups) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    f32x4 v[8];
+    float* base = w + gi * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + 4 * i);      // the whole group is read before it is overwritten
+    h8 hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[i][e];
+            const _Float16 h = (_Float16)x;
+            hi[i >> 1][4 * (i & 1) + e] = h;
+            lo[i >> 1][4 * (i & 1) + e] = (_Float16)(x - (float)h);
+        }
+    h8* out = reinterpret_cast<h8*>(base);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { out[i] = hi[i]; out[4 + i] = lo[i]; }
+}
+}  // namespace
+
+const char* glc_launch_presplit(hipStream_t st, void* w, size_t n) {
+    if (!w || n % 32) return "presplit: element count must be a multiple of 32";
+    const size_t groups = n / 32;
+    if (groups) hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (float*)w, groups);
+    return nullptr;
+}
+
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n) {
     if (!src || !dst) return "convert: null";
     if (n == 0) return nullptr;

@@ -18,6 +18,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 TOL_PROB = {"f32": 1e-4, "f16": 1e-2, "bf16": 6e-2}
 TOL_HID = {"f32": 2e-4, "f16": 6e-2, "bf16": 4e-1}
 GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*_b*_s*.npz")))
@@ -435,3 +437,29 @@ def test_randomised_shape_sweep(cname, dtype, engines, weights_for):
         assert got.shape == ref.shape, (case, B, S, lpr)
         if ref.size:
             assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (case, B, S, lpr)
+
+
+@pytest.mark.parametrize("gemm,attn", [("native", "native"), ("split", "native"), ("native", "split")])
+def test_fp32_mode_kernel_choices_agree(gemm, attn, tmp_path):
+    """The fp32 mode's split-f16 products (default) and the plain fp32-MFMA kernels (GLICLASS_F32_GEMM / GLICLASS_F32_ATTN = native)
+    are interchangeable: every combination stays inside the f32 bound against the oracle.  (Own process: the switches are read once.)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, 'oracle')!r}]\n"
+        "import oracle_c\n"
+        "from gliclass.c_amd import synth, weights\n"
+        "from gliclass.c_amd.config import CONFIGS\n"
+        "from gliclass.c_amd.engine import Engine\n"
+        "cfg = CONFIGS['mini']; w = weights.make_weights(cfg, 42)\n"
+        "ids, mask, _ = synth.make_inputs(cfg, 3, 700, 4, seed=5, ragged=True)\n"
+        "ref = oracle_c.forward(cfg, w, ids, mask)\n"
+        "got = Engine(cfg, w, dtype='f32').forward(ids, mask)\n"
+        "sig = lambda x: 1 / (1 + np.exp(-x.astype(np.float64)))\n"
+        "print('ERR', float(np.abs(sig(got) - sig(ref)).max()))\n")
+    env = dict(os.environ, GLICLASS_F32_GEMM=gemm, GLICLASS_F32_ATTN=attn)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = float(r.stdout.strip().split("ERR")[-1])
+    assert err <= 1e-4, (gemm, attn, err)

@@ -106,8 +106,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    if world > 1:      # N ranks on one node generate their synthetic weights at the same time: share the host cores between them
-        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
+    # host threads: the CPUs this job may really use (affinity / cgroup quota, not the 256 a GPU box shows), shared between the
+    # N ranks of one node, which generate their synthetic weights at the same time
+    from gliclass.c_amd.hostinfo import effective_cpus
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(effective_cpus(), 64) // max(world, 1))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import torch
     dist = None
     if world > 1 or os.environ.get("GLC_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU

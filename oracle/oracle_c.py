@@ -34,32 +34,10 @@ _lib = None
 
 
 def effective_cpus():
-    """CPUs this process can really use: min(affinity mask, cgroup CPU quota, online CPUs).  A GPU box shows all of its 128
-    cores but gives a job a share of them; a 128-thread OpenMP team spinning at its barriers inside a CFS quota makes the oracle
-    crawl (minutes instead of seconds), so the team is sized to the share."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
-            else:
-                quota = int(txt[0])
-                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if quota > 0 and period > 0:
-                    n = min(n, max(1, -(-quota // period)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    env = os.environ.get("GLO_THREADS") or os.environ.get("OMP_NUM_THREADS")
-    if env and env.isdigit() and int(env) > 0:
-        n = min(n, int(env))
-    return max(1, n)
+    """CPUs this process can really use (affinity, cgroup quota): the OpenMP team of the oracle is sized to it — a 256-thread team
+    spinning inside a 16-CPU quota made one 2-second forward take minutes on a GPU box."""
+    from gliclass.c_amd.hostinfo import effective_cpus as f
+    return f()
 
 
 def lib():

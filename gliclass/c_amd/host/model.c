@@ -12,6 +12,7 @@
 #include "model.h"
 
 #include <omp.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -120,11 +121,100 @@ OrtSession* create_ort_session(OrtEnv* env, const char* model_path, int num_thre
             return NULL;
         }
         s->engines[s->n_engines] = e;
+        pthread_mutex_init(&s->q[s->n_engines].mu, NULL);
+        pthread_cond_init(&s->q[s->n_engines].cv, NULL);
         s->devices[s->n_engines++] = devs[i];
+    }
+    {
+        const char* cr = getenv("GLICLASS_COALESCE_ROWS");
+        s->coalesce_rows = (cr && *cr) ? atoi(cr) : 64;
     }
     glc_weights_free(&w);
     printf("\tUsing MI355X HIP engine on %d GPU(s).\n", s->n_engines);
     return s;
+}
+
+/*
+ * Request coalescing.  The reference calls run_inference from an OpenMP team, one batch of BATCH_SIZE = 8 texts per call
+ * (/root/reference/main.c:141-149, include/configs.h:4); a forward of 8 rows leaves most of an MI355X idle.  Calls that arrive
+ * while the engine is busy queue up; whichever caller finds the engine free becomes the leader and serves the queue: it takes
+ * waiting calls in arrival order while their rows fit `coalesce_rows`, pads them to the longest sequence among them (pad id,
+ * mask 0 — exactly what pad-to-longest does inside one batch, /root/reference/src/tokenizer.c:77-81), runs ONE forward and
+ * hands every caller its own rows.  Rows are independent end to end, so each caller gets what it would have got alone — to
+ * 1e-6 in the fp32 mode (tests/test_cli.py compares printed scores), and to the operand-rounding noise of the 16-bit modes
+ * (a forward of 8 rows and one of 64 use different GEMM tile kernels, i.e. different fp32 summation orders before the f16 rounding).
+ * GLICLASS_COALESCE_ROWS (default 64; 0 = off).
+ */
+static void run_group(OrtSession* s, glc_engine* e, glc_req** g, int n) {
+    int ok = 1;
+    if (n == 1) {
+        int c_out = 0;
+        ok = glc_engine_forward(e, g[0]->ids, g[0]->mask, g[0]->B, g[0]->S, g[0]->logits, g[0]->C, &c_out) == 0;
+    } else {
+        int Bt = 0, Sm = 0, Cm = 0;
+        for (int i = 0; i < n; ++i) { Bt += g[i]->B; if (g[i]->S > Sm) Sm = g[i]->S; if (g[i]->C > Cm) Cm = g[i]->C; }
+        int64_t* ids = (int64_t*)malloc((size_t)Bt * Sm * sizeof(int64_t));
+        int64_t* mask = (int64_t*)calloc((size_t)Bt * Sm, sizeof(int64_t));
+        float* lg = (float*)calloc((size_t)Bt * (Cm ? Cm : 1), sizeof(float));
+        ok = ids && mask && lg;
+        if (ok) {
+            int row = 0;
+            for (int i = 0; i < n; ++i)
+                for (int b = 0; b < g[i]->B; ++b, ++row) {
+                    int64_t* di = ids + (size_t)row * Sm;
+                    memcpy(di, g[i]->ids + (size_t)b * g[i]->S, (size_t)g[i]->S * sizeof(int64_t));
+                    for (int t = g[i]->S; t < Sm; ++t) di[t] = s->cfg.pad_id;
+                    memcpy(mask + (size_t)row * Sm, g[i]->mask + (size_t)b * g[i]->S, (size_t)g[i]->S * sizeof(int64_t));
+                }
+            int c_out = 0;
+            ok = glc_engine_forward(e, ids, mask, Bt, Sm, lg, Cm, &c_out) == 0;
+            row = 0;
+            for (int i = 0; i < n && ok; ++i)
+                for (int b = 0; b < g[i]->B; ++b, ++row)
+                    for (int j = 0; j < g[i]->C; ++j) g[i]->logits[(size_t)b * g[i]->C + j] = lg[(size_t)row * Cm + j];
+        } else fprintf(stderr, "Error during inference: out of memory\n");
+        free(ids); free(mask); free(lg);
+    }
+    if (!ok) fprintf(stderr, "Error during inference: %s\n", glc_last_error());
+    for (int i = 0; i < n; ++i) g[i]->status = ok ? 1 : -1;     /* published under the queue lock by the caller */
+}
+
+static void serve_coalesced(OrtSession* s, int qi, glc_req* mine) {
+    glc_queue* q = &s->q[qi];
+    pthread_mutex_lock(&q->mu);
+    if (q->tail) q->tail->next = mine; else q->head = mine;
+    q->tail = mine;
+    if (q->busy) {                                   /* a leader is serving this engine: wait until it has done my call */
+        while (mine->status == 0 && q->busy) pthread_cond_wait(&q->cv, &q->mu);
+        if (mine->status != 0) { pthread_mutex_unlock(&q->mu); return; }
+        /* the leader left before reaching my call (cannot happen: it leaves only on an empty queue) — fall through and lead */
+    }
+    q->busy = 1;
+    while (q->head) {
+        glc_req* g[64];
+        int n = 0, rows = 0;
+        while (q->head && n < 64 && (n == 0 || rows + q->head->B <= s->coalesce_rows)) {
+            g[n++] = q->head; rows += q->head->B;
+            q->head = q->head->next;
+        }
+        if (!q->head) q->tail = NULL;
+        pthread_mutex_unlock(&q->mu);
+        int status[64];
+        glc_req tmp[64];
+        for (int i = 0; i < n; ++i) tmp[i] = *g[i];              /* work on copies: a caller's struct is only written under the lock */
+        {
+            glc_req* gp[64];
+            for (int i = 0; i < n; ++i) gp[i] = &tmp[i];
+            run_group(s, s->engines[qi], gp, n);
+            for (int i = 0; i < n; ++i) status[i] = tmp[i].status;
+        }
+        pthread_mutex_lock(&q->mu);
+        for (int i = 0; i < n; ++i) g[i]->status = status[i];
+        pthread_cond_broadcast(&q->cv);
+    }
+    q->busy = 0;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
 }
 
 static OrtValue* run_on_engine(OrtSession* s, glc_engine* e, OrtValue* ids_t, OrtValue* mask_t) {
@@ -144,11 +234,19 @@ static OrtValue* run_on_engine(OrtSession* s, glc_engine* e, OrtValue* ids_t, Or
     }
     float* logits = (float*)calloc((size_t)B * (C ? C : 1), sizeof(float));
     if (!logits) { fprintf(stderr, "Error during inference: out of memory\n"); return NULL; }
-    int c_out = 0;
-    if (glc_engine_forward(e, ids, (const int64_t*)mask_t->data, B, S, logits, C, &c_out) != 0) {
-        fprintf(stderr, "Error during inference: %s\n", glc_last_error());
-        free(logits);
-        return NULL;
+    int qi = 0;
+    while (qi < s->n_engines && s->engines[qi] != e) ++qi;
+    if (s->coalesce_rows > 1 && qi < s->n_engines) {
+        glc_req r = {ids, (const int64_t*)mask_t->data, B, S, C, logits, 0, NULL};
+        serve_coalesced(s, qi, &r);
+        if (r.status != 1) { free(logits); return NULL; }
+    } else {
+        int c_out = 0;
+        if (glc_engine_forward(e, ids, (const int64_t*)mask_t->data, B, S, logits, C, &c_out) != 0) {
+            fprintf(stderr, "Error during inference: %s\n", glc_last_error());
+            free(logits);
+            return NULL;
+        }
     }
     int64_t dims[2] = {B, C};
     OrtValue* out = glc_value_new(ONNX_TENSOR_ELEMENT_DATA_TYPE_FLOAT, dims, 2, logits, 1);

@@ -44,7 +44,7 @@ static void api_ReleaseEnv(OrtEnv* env) { free(env); }
 
 static void api_ReleaseSession(OrtSession* s) {
     if (!s) return;
-    for (int i = 0; i < s->n_engines; ++i) glc_engine_destroy(s->engines[i]);
+    for (int i = 0; i < s->n_engines; ++i) { glc_engine_destroy(s->engines[i]); pthread_mutex_destroy(&s->q[i].mu); pthread_cond_destroy(&s->q[i].cv); }
     free(s);
 }
 static void api_ReleaseValue(OrtValue* v) {

@@ -6,11 +6,11 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/glc_asan}
 mkdir -p "$OUT"
 cd "$REPO/gliclass/c_amd"
-for f in model ort_shim glc_weights parallel_processor postprocessor preprocessor; do
-    gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -fPIC -I../../include -c host/$f.c -o "$OUT/$f.o"
+for f in model ort_shim glc_weights parallel_processor postprocessor preprocessor tokenizer glc_json read_data glc_safetensors; do
+    gcc -O1 -g -D_GNU_SOURCE -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -fPIC -I../../include -c host/$f.c -o "$OUT/$f.o"
 done
 gcc -shared -fsanitize=address,undefined -fopenmp -o "$OUT/libgliclass_model.so" "$OUT"/*.o -L. -lgliclass_hip -Wl,-rpath,"$PWD" -lm
 cd "$REPO"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" GLC_MODEL_SO="$OUT/libgliclass_model.so" \
-    python -m pytest tests/test_host.py -x -q
+    python -m pytest tests/test_host.py tests/test_tokenizer.py -x -q -k "not live"

@@ -138,3 +138,30 @@ def test_pipelined_stages_print_the_same_blocks_in_batch_order(workdir):
         assert sorted(piped) == sorted(three_phase) and len(piped) == len(texts)
         order = [int(re.match(r"Text_\d+: (\d+): ", blk).group(1)) for blk in piped]
         assert order == list(range(len(texts)))                                        # deterministic: batch order, then row order
+
+
+@pytest.mark.gpu
+def test_multi_engine_session_on_one_gpu(workdir):
+    """The single-process multi-GPU path of the drop-in layer (GLICLASS_DEVICES lists the engines of a session; run_inference deals
+    concurrent calls round-robin, every engine has its own coalescing queue) exercised with two engines on the ONE GPU of a test box:
+    same printed blocks, same order as the single-engine session."""
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    cfg = dataclasses.replace(CONFIGS["tiny"], name="tiny-tok", vocab=6003, class_token_index=6001, text_token_index=6002)
+    blob = str(workdir / "tiny_tok_m.glcw")
+    weights.write_blob(blob, cfg, weights.make_weights(cfg, 3))
+    texts = [f"{i}: " + TEXTS[i % len(TEXTS)] for i in range(41)]
+    (workdir / "multi.json").write_text(json.dumps({"texts": texts, "labels": [LABELS], "same_labels": True, "classification_type": "multi-label"}))
+
+    def run(devices, pipeline):
+        env = dict(os.environ, GLICLASS_DTYPE="f32", GLICLASS_THRESHOLD="0.3", GLICLASS_BATCH_SIZE="4", GLICLASS_DEVICES=devices,
+                   GLICLASS_PIPELINE=pipeline)
+        r = subprocess.run([EXE, str(workdir / "multi.json"), "true", str(workdir / "tok.json"), blob], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert f"on {len(devices.split(','))} GPU(s)" in r.stdout
+        body = r.stdout.split("DONE: create_ort_session;\n\n", 1)[1].rsplit("Execution time:", 1)[0]
+        return [blk for blk in body.split("\n\n") if blk.strip()]
+
+    one = run("0", "1")
+    assert run("0,0", "1") == one                          # pipelined: ordered retirement -> identical output
+    assert sorted(run("0,0,0", "0")) == sorted(one)        # three phases (parallel_inference: one host thread per engine)

@@ -248,9 +248,27 @@ const char* glc_launch_attention_gqa(hipStream_t st, int dtype, int impl, const 
 
 namespace {
 
-template <typename T, int D>
+// SPLIT (T = float, the fp32 mode): the outputs are split-f16 units — the 32 bytes a lane owns of an 8-element unit hold
+// [8 hi halves | 8 lo halves] (glc_common.h f16x8s), at the addresses of the fp32 fragment-major layout.
+template <typename T, bool SPLIT> __device__ __forceinline__ void store_unit8(T* dst, const float (&v)[8]) {
+    if constexpr (SPLIT) {
+        f16x8s u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const f16_t hv = (f16_t)v[j]; u.hi[j] = hv; u.lo[j] = (f16_t)(v[j] - (float)hv); }
+        *reinterpret_cast<f16x8s*>(dst) = u;
+    } else {
+        typedef __attribute__((ext_vector_type(8))) T vec8;
+        vec8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (T)v[j];
+        *reinterpret_cast<vec8*>(dst) = o;
+    }
+}
+
+template <typename T, int D, bool SPLIT = false>
 __global__ __launch_bounds__(256) void qkv_layout_kernel(const T* __restrict__ QKV, const float* __restrict__ cs, T* __restrict__ Qf,
                                                          T* __restrict__ Kf, T* __restrict__ Vt, int Sp, int nq, int nkv, float qscale) {
+    static_assert(!SPLIT || sizeof(T) == 4, "split units live in the fp32 layouts");
     typedef __attribute__((ext_vector_type(8))) T vec8;
     constexpr int HD2 = D / 2, NS = D / 16;
     __shared__ T vs[32][D + 8];
@@ -268,18 +286,18 @@ __global__ __launch_bounds__(256) void qkv_layout_kernel(const T* __restrict__ Q
             const vec8 bq = *reinterpret_cast<const vec8*>(src + HD2);
             const float* c = cs + ((size_t)s * HD2 + c8 * 8) * 2;
             const float sc = isq ? qscale : 1.f;
-            vec8 o1, o2;
+            float o1[8], o2[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float co = c[2 * j], sn = c[2 * j + 1], x1 = (float)a[j], x2 = (float)bq[j];
-                o1[j] = (T)((x1 * co - x2 * sn) * sc);
-                o2[j] = (T)((x2 * co + x1 * sn) * sc);
+                o1[j] = (x1 * co - x2 * sn) * sc;
+                o2[j] = (x2 * co + x1 * sn) * sc;
             }
             const int lr = isq ? r : glc_pi32(r);                              // K rows sit at lane pi(r)
             T* dst = isq ? Qf + (((size_t)(b * nq + head) * nt + st) * NS) * 512 : Kf + (((size_t)(b * nkv + (head - nq)) * nt + st) * NS) * 512;
             const int d1 = c8 * 8, d2 = d1 + HD2;
-            *reinterpret_cast<vec8*>(dst + ((size_t)(d1 >> 4) * 64 + 32 * ((d1 >> 3) & 1) + lr) * 8) = o1;
-            *reinterpret_cast<vec8*>(dst + ((size_t)(d2 >> 4) * 64 + 32 * ((d2 >> 3) & 1) + lr) * 8) = o2;
+            store_unit8<T, SPLIT>(dst + ((size_t)(d1 >> 4) * 64 + 32 * ((d1 >> 3) & 1) + lr) * 8, o1);
+            store_unit8<T, SPLIT>(dst + ((size_t)(d2 >> 4) * 64 + 32 * ((d2 >> 3) & 1) + lr) * 8, o2);
         }
     } else {
         // ---- V head: transpose the 32 x D tile through LDS ----
@@ -293,22 +311,27 @@ __global__ __launch_bounds__(256) void qkv_layout_kernel(const T* __restrict__ Q
         for (int u = t; u < (D / 32) * 2 * 64; u += 256) {                     // unit = (dt, tt, lane)
             const int lane = u & 63, tt = (u >> 6) & 1, dt = u >> 7;
             const int dd = 32 * dt + (lane & 31), k0 = 16 * tt + 8 * (lane >> 5);
-            vec8 o;
+            float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = vs[k0 + j][dd];
-            *reinterpret_cast<vec8*>(dst + (size_t)u * 8) = o;
+            for (int j = 0; j < 8; ++j) o[j] = (float)vs[k0 + j][dd];
+            store_unit8<T, SPLIT>(dst + (size_t)u * 8, o);
         }
     }
 }
 
 constexpr float DEC_RESCALE_THR = 8.0f;   // log2 units (attention.hip)
 
-template <typename T, int D>
-__global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restrict__ Qf, const T* __restrict__ Kf, const T* __restrict__ Vt,
+template <bool SPLIT, typename T> struct GqaFrag { typedef typename Frag<T>::type type; };
+template <typename T> struct GqaFrag<true, T> { typedef f16x8s type; };
+// SPLIT (T = float): operands are split-f16 units, every product is three f16 MFMAs (glc_common.h), the probabilities are split on
+// the fly; one wave per SIMD (the doubled fragment sets need > 256 registers at D = 128).
+template <typename T, int D, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const T* __restrict__ Qf, const T* __restrict__ Kf, const T* __restrict__ Vt,
                                                                const float* __restrict__ kbias, const int* __restrict__ klen,
                                                                const int* __restrict__ kfirst_, T* __restrict__ CTX, int B, int Sp, int nq,
                                                                int nkv, int causal) {
-    typedef typename Frag<T>::type frag_t;
+    static_assert(!SPLIT || sizeof(T) == 4, "split units live in the fp32 layouts");
+    typedef typename GqaFrag<SPLIT, T>::type frag_t;
     constexpr int NS = D / 16, ND = D / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -413,8 +436,13 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restri
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             frag_t pfr;
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+                for (int j = 0; j < 8; ++j) { const f16_t ph = (f16_t)sv[8 * t + j]; pfr.hi[j] = ph; pfr.lo[j] = (f16_t)(sv[8 * t + j] - (float)ph); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+            }
 #pragma unroll
             for (int a = 0; a < ND; ++a) mma32(vt[a][t], pfr, o[a]);        // O^T[dd = 32a + (i&3) + 8(i>>2) + 4h][query c]
         }
@@ -429,19 +457,19 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mfma_kernel(const T* __restri
             store4<T>(out + 32 * a + 8 * gq + 4 * h, o[a][4 * gq] * inv, o[a][4 * gq + 1] * inv, o[a][4 * gq + 2] * inv, o[a][4 * gq + 3] * inv);
 }
 
-template <typename T> const char* launch_layout_t(hipStream_t st, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,
+template <typename T, bool SPLIT = false> const char* launch_layout_t(hipStream_t st, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,
                                                   int nq, int nkv, int d, float qscale) {
     const dim3 grid(B * Sp / 32, nq + 2 * nkv), block(256);
-    if (d == 128) hipLaunchKernelGGL((qkv_layout_kernel<T, 128>), grid, block, 0, st, (const T*)QKV, cs, (T*)Qf, (T*)Kf, (T*)Vt, Sp, nq, nkv, qscale);
-    else hipLaunchKernelGGL((qkv_layout_kernel<T, 64>), grid, block, 0, st, (const T*)QKV, cs, (T*)Qf, (T*)Kf, (T*)Vt, Sp, nq, nkv, qscale);
+    if (d == 128) hipLaunchKernelGGL((qkv_layout_kernel<T, 128, SPLIT>), grid, block, 0, st, (const T*)QKV, cs, (T*)Qf, (T*)Kf, (T*)Vt, Sp, nq, nkv, qscale);
+    else hipLaunchKernelGGL((qkv_layout_kernel<T, 64, SPLIT>), grid, block, 0, st, (const T*)QKV, cs, (T*)Qf, (T*)Kf, (T*)Vt, Sp, nq, nkv, qscale);
     return nullptr;
 }
-template <typename T> const char* launch_gqa_t(hipStream_t st, const void* Qf, const void* Kf, const void* Vt, const float* kbias, const int* klen,
+template <typename T, bool SPLIT = false> const char* launch_gqa_t(hipStream_t st, const void* Qf, const void* Kf, const void* Vt, const float* kbias, const int* klen,
                                                const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal) {
     const int nt = Sp / 32, nqb = (nt + 3) / 4, per = (nq / nkv) * nqb, bg8 = (B * nkv + 7) / 8 * 8;
     const dim3 grid(per * bg8), block(256);
-    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
-    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
+    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
+    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
     return nullptr;
 }
 
@@ -453,7 +481,8 @@ const char* glc_launch_qkv_layout(hipStream_t st, int dtype, const void* QKV, co
     if (!QKV || !cs || !Qf || !Kf || !Vt || B <= 0 || Sp <= 0 || Sp % 64 || nq <= 0 || nkv <= 0 || (d != 64 && d != 128)) return "qkv_layout: bad args";
     if (dtype == GLC_DT_BF16) return launch_layout_t<bf16_t>(st, QKV, cs, Qf, Kf, Vt, B, Sp, nq, nkv, d, qscale);
     if (dtype == GLC_DT_F16) return launch_layout_t<f16_t>(st, QKV, cs, Qf, Kf, Vt, B, Sp, nq, nkv, d, qscale);
-    return "qkv_layout: 16-bit operands only";
+    if (dtype == GLC_DT_F32) return launch_layout_t<float, true>(st, QKV, cs, Qf, Kf, Vt, B, Sp, nq, nkv, d, qscale);    // fp32 data -> split-f16 units
+    return "qkv_layout: bad dtype";
 }
 
 // MFMA grouped-query attention on the fragment-major operands written by glc_launch_qkv_layout.  CTX [B*Sp, nq*d] row-major.
@@ -464,5 +493,6 @@ const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void*
         return "attention_gqa_mfma: bad args";
     if (dtype == GLC_DT_BF16) return launch_gqa_t<bf16_t>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);
     if (dtype == GLC_DT_F16) return launch_gqa_t<f16_t>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);
-    return "attention_gqa_mfma: 16-bit operands only";
+    if (dtype == GLC_DT_F32) return launch_gqa_t<float, true>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);   // split-f16 units
+    return "attention_gqa_mfma: bad dtype";
 }

@@ -65,6 +65,7 @@ struct glc_engine {
     int dtype = GLC_F32, device = 0, attn_impl = 0;
     bool prune_last = true;         // last layer only on the rows the head reads (exact)
     bool w_presplit = false;        // weights of the split-f16 fp32 GEMMs are split once at load (encoder layers in fp32 mode; head projectors in every mode)
+    bool dec_split = false;         // decoder backbone, fp32 mode: RoPE/layout pass writes split-f16 units, grouped-query attention on three-MFMA products
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
@@ -177,7 +178,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
         dfree(e, e->QKV); e->QKV = dmalloc(e, (size_t)Mpad * (nqd + 2 * nkvd) * es); if (!e->QKV) return false;
         dfree(e, e->CTX); e->CTX = dmalloc(e, (size_t)Mpad * nqd * es); if (!e->CTX) return false;
-        if (e->dtype != GLC_F32) {          // fragment-major operands of the MFMA attention kernel
+        if (e->dtype != GLC_F32 || e->dec_split) {          // fragment-major operands of the MFMA attention kernel (fp32 mode: split-f16 units, same bytes)
             dfree(e, e->Qh); e->Qh = dmalloc(e, (size_t)Mpad * nqd * es); if (!e->Qh) return false;
             dfree(e, e->Kh); e->Kh = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Kh) return false;
             dfree(e, e->Vt); e->Vt = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Vt) return false;
@@ -320,7 +321,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
       KCHK(glc_launch_embed_plain(st, dt, ids, mask, e->emb, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     const float qscale = 1.4426950408889634f / sqrtf((float)d);         // Q2:186 scaling, times log2(e) for the exp2 softmax
-    const bool mfma = dt != GLC_F32 && e->attn_impl != 1;               // 16-bit: flash-style MFMA kernel; fp32 / impl 1: straightforward kernel
+    const bool mfma = (dt != GLC_F32 || e->dec_split) && e->attn_impl != 1;   // flash-style MFMA kernel (fp32 mode: on split-f16 units); impl 1 / native fp32: straightforward kernel
     void *X = e->X, *Xn = e->X2;
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = e->dlayers[l];
@@ -623,6 +624,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     if (e->cfg.kv_heads <= 0) e->cfg.kv_heads = e->cfg.heads;
     if (const char* pv = getenv("GLICLASS_PRUNE_LAST")) e->prune_last = atoi(pv) != 0;
     { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
+    { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {

@@ -12,7 +12,8 @@
  *      them as the reference's three phases)
  *   release                           (main.c:173-187)
  *
- * usage: gliclass_main /path/to/data.json <prompt_first: true|false> [tokenizer.json] [model.glcw | synthetic:cfg[:seed]]
+ * usage: gliclass_main /path/to/data.json <prompt_first: true|false|auto> [tokenizer.json] [model dir | model.glcw | synthetic:cfg[:seed]]
+ *   (auto = `prompt_first` of the model directory's config.json, the job of run_GLiClass.sh:84-89)
  *   (the two optional arguments default to GLICLASS_TOKENIZER / GLICLASS_MODEL, then include/paths.h)
  * build: make -C gliclass/c_amd gliclass_main
  */
@@ -20,6 +21,7 @@
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "configs.h"
 #include "model.h"
@@ -50,7 +52,12 @@ int main(int argc, char* argv[]) {
 
     char* json_string = read_file(argv[1]);
     if (!json_string) return 1;
-    bool prompt_first = string_to_bool(argv[2]);
+    bool prompt_first;
+    if (strcmp(argv[2], "auto") == 0) {          /* what run_GLiClass.sh:84-89 does with jq: take it from the model's config.json */
+        int pf = glc_config_prompt_first(pick(argc, argv, 4, "GLICLASS_MODEL", MODEL_PATH));
+        if (pf < 0) return 1;
+        prompt_first = pf != 0;
+    } else prompt_first = string_to_bool(argv[2]);
     parse_json(json_string, &texts, &num_texts, &labels, &num_labels, &num_labels_size, &same_labels, &classification_type);
     printf("DONE: parse_json;\n");
     if (classification_type == NULL) {

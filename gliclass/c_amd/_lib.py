@@ -54,7 +54,7 @@ MODEL_SYMBOLS = ["flatten_int_array", "create_tensor", "prepare_input_tensors", 
                  "tokenizers_free_encode_results", "tokenizers_decode", "tokenizers_get_decode_str", "tokenizers_get_vocab_size",
                  "tokenizers_id_to_token", "tokenizers_token_to_id", "tokenizers_free", "glc_tokenizer_normalize",
                  "tokenize_inputs", "print_tokenized_inputs", "free_tokenized_inputs", "create_tokenizer",
-                 "read_file", "parse_json", "string_to_bool", "free_parsed_data", "glc_load_hf_checkpoint", "parallel_classify"]
+                 "read_file", "parse_json", "string_to_bool", "free_parsed_data", "glc_load_hf_checkpoint", "parallel_classify", "glc_config_prompt_first"]
 
 _hip = None
 _model = None

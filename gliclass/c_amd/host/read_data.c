@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include "glc_json.h"
 
@@ -115,6 +116,29 @@ bool string_to_bool(const char* str) {
     if (strcmp(str, "false") == 0 || strcmp(str, "0") == 0) return false;
     printf("Invalid value for bool argument. Use 'true' or 'false'.\n");
     exit(1);                                                                         /* as the reference (:165-166) */
+}
+
+int glc_config_prompt_first(const char* model_path) {
+    char path[4096];
+    struct stat sb;
+    if (!model_path || stat(model_path, &sb) != 0) { fprintf(stderr, "Error: cannot open model '%s'\n", model_path ? model_path : "(null)"); return -1; }
+    if (S_ISDIR(sb.st_mode)) snprintf(path, sizeof path, "%s/config.json", model_path);
+    else {
+        snprintf(path, sizeof path, "%s", model_path);
+        char* slash = strrchr(path, '/');
+        snprintf(slash ? slash + 1 : path, sizeof path - (size_t)(slash ? slash + 1 - path : 0), "config.json");
+    }
+    char* text = read_file(path);
+    if (!text) return -1;
+    char err[160];
+    gj_doc* doc = gj_parse(text, strlen(text), 0, err, sizeof err);
+    free(text);
+    if (!doc) { fprintf(stderr, "Error: %s: %s\n", path, err); return -1; }
+    const gj_value* v = gj_get(gj_root(doc), "prompt_first");
+    int r = gj_is(v, GJ_BOOL) ? (v->u.boolean ? 1 : 0) : -1;
+    gj_free(doc);
+    if (r < 0) fprintf(stderr, "Something wrong with model configuration file.\nExpected values: 'true' or 'false' for prompt_first in %s\n", path);
+    return r;
 }
 
 void free_parsed_data(char** texts, size_t num_texts, char*** labels, size_t* num_labels, bool same_labels,

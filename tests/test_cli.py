@@ -46,6 +46,15 @@ def test_usage_and_front_half_without_gpu(workdir):
     assert r.returncode == 1 and "classification type is not provided" in r.stdout    # main.c:71-74
     r = subprocess.run([EXE, data, "true", str(workdir / "missing.json")], capture_output=True, text=True)
     assert r.returncode == 1 and "Cant open file" in r.stderr                          # tokenizer.c:149
+    # prompt_first = auto: read from the model directory's config.json (run_GLiClass.sh:84-89)
+    mdir = workdir / "model_dir"
+    mdir.mkdir(exist_ok=True)
+    (mdir / "config.json").write_text(json.dumps({"prompt_first": "yes"}))
+    r = subprocess.run([EXE, data, "auto", str(workdir / "tok.json"), str(mdir)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Something wrong with model configuration file." in r.stderr
+    (mdir / "config.json").write_text(json.dumps({"prompt_first": True, "encoder_config": {}}))
+    r = subprocess.run([EXE, data, "auto", str(workdir / "tok.json"), str(mdir)], capture_output=True, text=True)
+    assert "DONE: create_tokenizer;" in r.stdout and r.returncode != 0          # got past prompt_first; the (empty) checkpoint is refused
     from gliclass.c_amd import _lib
     if _lib.hip().glc_device_count() == 0:
         r = subprocess.run([EXE, data, "true", str(workdir / "tok.json"), "synthetic:tiny"], capture_output=True, text=True)

@@ -425,10 +425,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     T* out = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + c) * a.H + hh * 64;
+    if constexpr (sizeof(T) == 2) {
+        store_acc32_wide<T>(o0, inv, out, h);          // 16-byte stores via v_permlane32_swap (glc_common.h)
+        store_acc32_wide<T>(o1, inv, out + 32, h);
+    } else {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        store4<T>(out + 8 * g + 4 * h, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-        store4<T>(out + 32 + 8 * g + 4 * h, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        for (int g = 0; g < 4; ++g) {
+            store4<T>(out + 8 * g + 4 * h, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            store4<T>(out + 32 + 8 * g + 4 * h, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
     }
 }
 

@@ -450,11 +450,16 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     T* out = CTX + ((size_t)b * Sp + q0 + c) * ((size_t)nq * D) + (size_t)hq * D;
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int a = 0; a < ND; ++a)
+        for (int a = 0; a < ND; ++a) store_acc32_wide<T>(o[a], inv, out + 32 * a, h);      // 16-byte stores via v_permlane32_swap (glc_common.h)
+    } else {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-            store4<T>(out + 32 * a + 8 * gq + 4 * h, o[a][4 * gq] * inv, o[a][4 * gq + 1] * inv, o[a][4 * gq + 2] * inv, o[a][4 * gq + 3] * inv);
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                store4<T>(out + 32 * a + 8 * gq + 4 * h, o[a][4 * gq] * inv, o[a][4 * gq + 1] * inv, o[a][4 * gq + 2] * inv, o[a][4 * gq + 3] * inv);
+    }
 }
 
 template <typename T, bool SPLIT = false> const char* launch_layout_t(hipStream_t st, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,

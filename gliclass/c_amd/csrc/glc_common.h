@@ -87,6 +87,25 @@ template <typename T> __device__ __forceinline__ void load4(const T* p, float& a
     a = (float)v[0]; b = (float)v[1]; c = (float)v[2]; d = (float)v[3];
 }
 
+// Epilogue store of one 32x32 MFMA accumulator o = O^T[dd][query] scaled by `inv`, 16-bit T: a query row's 32 outputs are split between
+// lane c (h = 0: columns 8g..8g+3) and lane c + 32 (columns 8g+4..8g+7).  One v_permlane32_swap per dword and pair of groups (2p, 2p+1)
+// hands lane c the whole 16 bytes of group 2p and lane c + 32 those of group 2p+1: two 16-byte stores per lane instead of four 8-byte
+// ones (the store tail of an attention wave is bound by store INSTRUCTIONS, not bytes: -1 % on the band kernel).  Same values, same
+// rounding, same addresses as store4 per group.  `base` = this query row's first of the 32 columns.
+template <typename T> __device__ __forceinline__ void store_acc32_wide(const f32x16& o, float inv, T* base, int h) {
+    static_assert(sizeof(T) == 2, "16-bit outputs");
+    typedef __attribute__((ext_vector_type(2))) T T2;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const T2 a0 = {(T)(o[8 * p] * inv), (T)(o[8 * p + 1] * inv)}, a1 = {(T)(o[8 * p + 2] * inv), (T)(o[8 * p + 3] * inv)};          // group 2p
+        const T2 b0 = {(T)(o[8 * p + 4] * inv), (T)(o[8 * p + 5] * inv)}, b1 = {(T)(o[8 * p + 6] * inv), (T)(o[8 * p + 7] * inv)};      // group 2p + 1
+        const auto rx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0), false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1), false, false);
+        const u32x4 v = {rx[0], ry[0], rx[1], ry[1]};      // h = 0: [own 2p | partner's 2p]; h = 1: [partner's 2p+1 | own 2p+1]
+        *reinterpret_cast<u32x4*>(base + 16 * p + 8 * h) = v;
+    }
+}
+
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e. at fp32 resolution for GELU's use)
 __device__ __forceinline__ float glc_erf(float x) {
     float ax = fabsf(x);

@@ -381,3 +381,16 @@ def test_native_hf_checkpoint_import(libs, tmp_path):
     (d / "config.json").write_text(json.dumps(_hf_config_json(cfg)))
     os.remove(d / "model.safetensors")
     assert model.glc_weights_load(str(d).encode(), C.byref(W)) != 0
+
+
+def test_effective_cpus_respects_affinity_and_env(monkeypatch):
+    """hostinfo.effective_cpus (python) and glc_host_cpus (C, host/glc_cpus.h) size thread teams to what the job may really use."""
+    from gliclass.c_amd import hostinfo
+    n = hostinfo.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
+    monkeypatch.setenv("OMP_NUM_THREADS", "1")
+    assert hostinfo.effective_cpus() == 1
+    monkeypatch.setenv("OMP_NUM_THREADS", "100000")
+    assert hostinfo.effective_cpus() == n or hostinfo.effective_cpus() <= (os.cpu_count() or 1)

@@ -814,6 +814,14 @@ static void plan_buckets(const std::vector<int>& len, int max_groups, const Buck
 int glc_engine_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, float* logits, int c_alloc, int* c_out) {
     if (!e || !ids || !mask || (!logits && c_alloc > 0)) { set_err("forward: null argument"); return -1; }
     if (!check_shape(e, B, S, c_alloc)) return -1;
+    // A class token under attention_mask 0 is outside the contract: its hidden state would be a padding-QUERY row (HF: uniform
+    // attention over every position), which this engine does not compute — refuse instead of returning a different number.  The
+    // reference's tokenizer never produces it (mask 1 on every real token, /root/reference/src/tokenizer.c:77-79).
+    for (size_t i = 0, n = (size_t)B * S; i < n; ++i)
+        if (mask[i] == 0 && ids[i] == e->cfg.class_token_index) {
+            set_err("forward: a class token (<<LABEL>>) lies under attention_mask 0 (row " + std::to_string(i / S) + ", position " + std::to_string(i % S) + "): not supported");
+            return -1;
+        }
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHK(hipSetDevice(e->device), -1);
     std::vector<int> cnt(B);

@@ -463,3 +463,18 @@ def test_fp32_mode_kernel_choices_agree(gemm, attn, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     err = float(r.stdout.strip().split("ERR")[-1])
     assert err <= 1e-4, (gemm, attn, err)
+
+
+def test_masked_class_token_is_refused(engines, weights_for):
+    """A <<LABEL>> token under attention_mask 0 would need a padding-QUERY row (HF: uniform attention over every position); the engine
+    does not compute those, so the host-buffer forward refuses the input instead of returning a different number."""
+    from gliclass.c_amd import synth
+    cfg, _ = weights_for("tiny")
+    eng = engines("tiny", "f32")
+    ids, mask, _ = synth.make_inputs(cfg, 2, 64, 3, seed=1)
+    pos = int(np.where(ids[0] == cfg.class_token_index)[0][1])
+    mask[0, pos] = 0
+    with pytest.raises(RuntimeError, match="class token"):
+        eng.forward(ids, mask)
+    mask[0, pos] = 1
+    assert np.isfinite(eng.forward(ids, mask)).all()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU soak: random shapes (B <= 12, S <= 1400, 0-8 labels per row, ragged rows, mask holes) for both backbones and every operand
-mode against the CPU oracle, for a time budget.  usage: gpu_soak.py [seconds=240] [seed=0].  Exit code 1 on any violation of the
+mode against the CPU oracle, for a time budget.  usage: gpu_soak.py [seconds=240] [seed=0] [max_S=1400] [models=tiny,mini,dec-tiny].  Exit code 1 on any violation of the
 tests' envelopes (f32 1e-4, f16 1e-2, bf16 6e-2) or a non-finite output."""
 import os
 import sys
@@ -22,18 +22,20 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    max_s = int(sys.argv[3]) if len(sys.argv) > 3 else 1400
+    names = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("tiny", "mini", "dec-tiny")
     models = {}
-    for cname in ("tiny", "mini", "dec-tiny"):
+    for cname in names:
         cfg = CONFIGS[cname]
         w = weights.make_weights(cfg, 42)
         models[cname] = (cfg, w, {dt: Engine(cfg, w, dtype=dt) for dt in TOL})
     worst = {(c, d): 0.0 for c in models for d in TOL}
     t0, cases, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
-        cname = ("tiny", "mini", "dec-tiny")[int(rng.integers(0, 3))]
+        cname = names[int(rng.integers(0, len(names)))]
         cfg, w, engs = models[cname]
         B = int(rng.integers(1, 13))
-        S = int(rng.integers(1, 1401)) if rng.random() < 0.8 else int(rng.integers(1, 48))
+        S = int(rng.integers(1, max_s + 1)) if rng.random() < 0.8 else int(rng.integers(1, 48))
         cmax = int(rng.integers(0, 9))
         lpr = [int(x) for x in rng.integers(0, cmax + 1, size=B)]
         S = max(S, 2 + 3 * max(lpr + [0]) + 2)

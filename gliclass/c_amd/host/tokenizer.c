@@ -23,8 +23,9 @@
  * Parity is pinned by tests/golden/tokenizer_golden.json.gz (ids produced by the python `tokenizers` wheel -- the same
  * Rust code -- on a DeBERTa-v3-structured tokenizer.json, see oracle/gen_tokenizer_fixture.py) and, where the wheel is
  * importable, by a live randomised comparison (tests/test_tokenizer.py).
- * Known approximations (none of them reachable with the DeBERTa-v3 file): prepend_scheme "first" looks at the position
- * of the piece in the split list, not at original offsets; `single_word` uses an ASCII + "any non-ASCII letter-ish"
+ * Known approximations (none of them reachable with the DeBERTa-v3 file): prepend_scheme "first" is decided from "first piece
+ * of the text AND the normalisers removed nothing at its start" (equal to the Rust library's original-offset test on every live
+ * probe, tests/test_tokenizer.py); `single_word` uses an ASCII + "any non-ASCII letter-ish"
  * notion of \w; the `padding` section is ignored (the reference pads itself, src/tokenizer.c:77-81).
  */
 #include "tokenizer.h"
@@ -372,10 +373,12 @@ static int precompiled_emit(const norm_step* st, const unsigned char* chunk, siz
     return 1;
 }
 
-static void norm_precompiled(const norm_step* st, const char* in, size_t n, sbuf* out) {
+static void norm_precompiled(const norm_step* st, const char* in, size_t n, sbuf* out, int* lead_removed) {
     const unsigned char* s = (const unsigned char*)in;
     size_t i = 0;
+    const size_t out0 = out->len;
     while (i < n) {
+        if (i > 0 && out->len == out0) *lead_removed = 1;          /* everything consumed so far was rewritten to nothing */
         size_t e = grapheme_end(s, i, n);
         if (e - i < 6 && precompiled_emit(st, s + i, e - i, out)) { i = e; continue; }
         while (i < e) {
@@ -387,7 +390,7 @@ static void norm_precompiled(const norm_step* st, const char* in, size_t n, sbuf
     }
 }
 
-static void norm_strip(const norm_step* st, const char* in, size_t n, sbuf* out) {
+static void norm_strip(const norm_step* st, const char* in, size_t n, sbuf* out, int* lead_removed) {
     const unsigned char* s = (const unsigned char*)in;
     size_t b = 0, e = n, adv;
     if (st->left) while (b < n) { uint32_t c = u8_decode(s + b, n - b, &adv); if (!is_white_space(c)) break; b += adv; }
@@ -400,6 +403,7 @@ static void norm_strip(const norm_step* st, const char* in, size_t n, sbuf* out)
             e = k;
         }
     }
+    if (b > 0) *lead_removed = 1;
     sb_put(out, in + b, e - b);
 }
 
@@ -452,16 +456,19 @@ static void norm_lowercase(const char* in, size_t n, sbuf* out) {
     }
 }
 
-/* Runs the whole chain; result in *a (b is scratch). */
-static void normalize_chain(const glc_tokenizer* tk, const char* in, size_t n, sbuf* a, sbuf* b) {
+/* Runs the whole chain; result in *a (b is scratch).  Returns 1 when the normalisers removed the START of the text (stripped
+ * whitespace, a leading character rewritten to nothing): the piece then no longer begins at original offset 0, which is what
+ * Metaspace's prepend_scheme "first" looks at. */
+static int normalize_chain(const glc_tokenizer* tk, const char* in, size_t n, sbuf* a, sbuf* b) {
+    int lead_removed = 0;
     sb_clear(a); sb_put(a, in, n);
-    if (!a->s) return;
+    if (!a->s) return 0;
     for (size_t k = 0; k < tk->nsteps; ++k) {
         const norm_step* st = &tk->steps[k];
         sb_clear(b); sb_reserve(b, a->len);
         switch (st->kind) {
-            case N_STRIP: norm_strip(st, a->s, a->len, b); break;
-            case N_PRECOMPILED: norm_precompiled(st, a->s, a->len, b); break;
+            case N_STRIP: norm_strip(st, a->s, a->len, b, &lead_removed); break;
+            case N_PRECOMPILED: norm_precompiled(st, a->s, a->len, b, &lead_removed); break;
             case N_REPLACE_LIT: norm_replace_lit(st, a->s, a->len, b); break;
             case N_REPLACE_RUN: norm_replace_run(st, a->s, a->len, b); break;
             case N_LOWERCASE: norm_lowercase(a->s, a->len, b); break;
@@ -471,6 +478,7 @@ static void normalize_chain(const glc_tokenizer* tk, const char* in, size_t n, s
         sbuf t = *a; *a = *b; *b = t;
         if (!a->s) { sb_put(a, "", 0); }
     }
+    return lead_removed;
 }
 
 /* ---------------------------------------------------------------- Unigram (Viterbi) */
@@ -645,7 +653,7 @@ static void on_raw_split(void* vctx, const char* s, size_t n, int32_t id) {
     if (id >= 0) { iv_push(c->out, id); c->first = 0; return; }
     if (!n) return;
     scratch* sc = c->sc;
-    normalize_chain(c->tk, s, n, &sc->norm_a, &sc->norm_b);
+    if (normalize_chain(c->tk, s, n, &sc->norm_a, &sc->norm_b)) c->first = 0;     /* no longer at original offset 0 */
     if (sc->norm_a.len) split_added(c->tk, 1, sc->norm_a.s, sc->norm_a.len, on_norm_split, c);   /* the pre-tokeniser uses other scratch buffers */
     c->first = 0;
 }

@@ -149,6 +149,11 @@ def _variants(js):
     yield "added-lstrip-rstrip", v(lambda j: set_added(j, lstrip=True, rstrip=True))
     yield "added-special-raw", v(lambda j: set_added(j, normalized=False, special=True))
     yield "metaspace-never", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(prepend_scheme="never"))
+    yield "metaspace-first", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(prepend_scheme="first"))
+    def first_special(j):
+        j["pre_tokenizer"]["pretokenizers"][0].update(prepend_scheme="first")
+        set_added(j, normalized=False, special=True)
+    yield "metaspace-first-special-added", v(first_special)
     yield "metaspace-nosplit", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(split=False))
     yield "lowercase", v(lambda j: j["normalizer"]["normalizers"].insert(0, {"type": "Lowercase"}))
     yield "no-normalizer", v(lambda j: j.update(normalizer=None))

@@ -25,8 +25,7 @@
  * importable, by a live randomised comparison (tests/test_tokenizer.py).
  * Known approximations (none of them reachable with the DeBERTa-v3 file): prepend_scheme "first" is decided from "first piece
  * of the text AND the normalisers removed nothing at its start" (equal to the Rust library's original-offset test on every live
- * probe, tests/test_tokenizer.py); `single_word` uses an ASCII + "any non-ASCII letter-ish"
- * notion of \w; the `padding` section is ignored (the reference pads itself, src/tokenizer.c:77-81).
+ * probe, tests/test_tokenizer.py); the `padding` section is ignored (the reference pads itself, src/tokenizer.c:77-81).
  */
 #include "tokenizer.h"
 
@@ -591,9 +590,9 @@ static void encode_text_piece(const glc_tokenizer* tk, const char* s, size_t n, 
     if (start < len) unigram_encode(tk, p + start, len - start, sc, out);
 }
 
-static int is_word_char(uint32_t c) {
+static int is_word_char(uint32_t c) {                /* \w of the Rust regex crate (table probed from the library, glc_unicode_tables.h) */
     if (c < 0x80) return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_';
-    return !is_white_space(c) && !(c >= 0x2000 && c <= 0x206F) && !(c >= 0x3000 && c <= 0x303F);
+    return range_lookup(glc_word_ranges, sizeof(glc_word_ranges) / sizeof(glc_word_ranges[0]), c);
 }
 
 /* AddedVocabulary::find_matches over patterns with the given `normalized` flag; calls cb for each split. */

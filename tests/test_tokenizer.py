@@ -147,6 +147,7 @@ def _variants(js):
                 a.update(kw)
     yield "base", js
     yield "added-lstrip-rstrip", v(lambda j: set_added(j, lstrip=True, rstrip=True))
+    yield "added-single-word", v(lambda j: set_added(j, single_word=True))
     yield "added-special-raw", v(lambda j: set_added(j, normalized=False, special=True))
     yield "metaspace-never", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(prepend_scheme="never"))
     yield "metaspace-first", v(lambda j: j["pre_tokenizer"]["pretokenizers"][0].update(prepend_scheme="first"))

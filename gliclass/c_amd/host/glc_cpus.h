@@ -11,7 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-static inline int glc_host_cpus(void) {
+static inline int glc_host_cpus_hw(void) {          /* affinity and cgroup quota: fixed for the life of the process */
     static int cached = 0;
     if (cached > 0) return cached;
     int n = omp_get_num_procs();
@@ -33,10 +33,15 @@ static inline int glc_host_cpus(void) {
         if (g) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
         if (quota > 0 && period > 0) { long c = (quota + period - 1) / period; if (c > 0 && c < n) n = (int)c; }
     }
-    int omp = omp_get_max_threads();
-    if (omp > 0 && omp < n) n = omp;
     if (n < 1) n = 1;
     cached = n;
+    return n;
+}
+
+static inline int glc_host_cpus(void) {
+    int n = glc_host_cpus_hw();
+    const int omp = omp_get_max_threads();           /* OMP_NUM_THREADS / omp_set_num_threads: may change at run time */
+    if (omp > 0 && omp < n) n = omp;
     return n;
 }
 #endif

@@ -45,7 +45,7 @@ constexpr int ROWP = ROWB + 16;    // padded LDS row stride (bytes)
 // maximum (65504); the engine checks nothing at run time, GLICLASS_F32_GEMM=native selects the plain fp32-MFMA kernel.
 // LDS image per row and stage (32 k): [32 hi halves | 32 lo halves] = the same 128 bytes as 32 floats.
 template <typename T, int EPI, bool SPLITK = false, bool SPLIT = false>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p, int ksplit) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p, int ksplit) {   // two workgroups per CU: the QKV epilogue variants otherwise take 284 registers (one wave per SIMD)
     static_assert(!SPLIT || sizeof(T) == 4, "the split path takes fp32 operands");
     typedef typename Frag<T>::type frag_t;
     constexpr int BK = ROWB / (int)sizeof(T);

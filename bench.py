@@ -3,19 +3,32 @@
 /root/reference/src/model.c:122-207) at BASELINE.json's config c3 — gliclass-base shape, batch 64,
 seq 1024, 8 labels — one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f16|bf16|f32] [--config base]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f16|bf16] [--config base|small|large|qwen-1.5b]
+                  [--batch B] [--seq S] [--labels C] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one forward over one batch whose token ids / mask are already resident in HBM
-(glc_engine_forward_device).  Every rank owns a full batch (weak scaling; sequences are
-independent, so there is no data-path collective — SURVEY.md §8e); value = N*B*K / max-over-ranks time.
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
+Launched WITHOUT a torch.distributed environment and with --gpus N > 1, this script starts the N ranks itself (fresh child
+processes, created before the parent touches the GPU), so `python bench.py --gpus 8` is a complete 8-GPU run.
+
+A step = one forward over one batch whose token ids / mask are already resident in HBM (glc_engine_forward_device).
+  --scaling weak   (default) every rank owns a full batch of --batch rows; no data-path collective (sequences are independent,
+                   SURVEY.md §8e); value = N*B*K / max-over-ranks time.
+  --scaling strong ONE global batch of --batch rows is partitioned contiguously over the ranks (the reference's batch loop,
+                   /root/reference/main.c:141-150, turned into a batch shard: c4 = `--config large --batch 256 --gpus 8` is 32 rows per
+                   GPU) and every step ends with the gather of the [B/G, C] logits to rank 0 (RCCL all-gather); value = B*K / time.
+
+The headline mode is the DEFAULT arithmetic mode of the product (GLICLASS_DTYPE unset = f32: fp32 data, every matrix product as
+split-f16 MFMAs), the mode that meets the 1e-3 probability tolerance; rank 0 checks it live against the CPU oracle and prints
+`parity_ok`.  The opt-in 16-bit throughput mode is measured beside it (`throughput_mode`), flagged with its own error.
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed on the engine's stream) and `cpu_baseline`
 (the C oracle — a port, not ONNXRuntime — on a bounded sample of the same workload).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,13 +37,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 2500.0}   # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md); the f32 mode runs f16 MFMAs too (x3 per product)
+MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32": 3}            # split-f16: a_lo*b_hi + a_hi*b_lo + a_hi*b_hi
+BAR = 1e-3                                                     # /root/reference/ONNX_CONVERTING/test_onnx.py:30
 
 
 def kernel_flops(cfg, B, S):
     """Algorithmic FLOPs of ONE launch of each kernel class (SURVEY.md §8d terms)."""
     H, I, P = cfg.hidden, cfg.inter, 2 * cfg.att_span
     M = B * S
+    if cfg.backbone == 1:          # decoder-style backbone (Qwen2 arithmetic)
+        nqd, nkvd = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+        kappa = 0.5 if cfg.causal else 1.0
+        return {
+            "gemm_qkv": 2.0 * M * H * (nqd + 2 * nkvd),
+            "attention": B * S * 4.0 * S * nqd * kappa,
+            "gemm_attn_out": 2.0 * M * nqd * H,
+            "gemm_ffn1_gelu": 2.0 * M * H * 2 * I,
+            "gemm_ffn2": 2.0 * M * I * H,
+        }
     return {
         "gemm_qkv": 2.0 * M * H * 3 * H,
         "attention": B * S * (4.0 * S * H + 4.0 * P * H),
@@ -58,32 +83,230 @@ def time_steps(step_fn, sync_fn, barrier_fn, max_fn, steps, warmup):
 
 
 def shard_rows(n_rows, world, rank):
-    """Contiguous batch split used when ONE batch is partitioned (strong mode / host sharding):
-    rank g gets rows [g*n/G, (g+1)*n/G)."""
+    """Contiguous batch split of the strong mode: rank g gets rows [g*n/G, (g+1)*n/G)."""
     lo = n_rows * rank // world
     hi = n_rows * (rank + 1) // world
     return lo, hi
 
 
-def cpu_baseline(cfg, wptrs, n_t, S, C_labels, seqs):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv, env_extra=None, timeout_s=3000):
+    """Start the N ranks of one node as fresh child processes (the parent has not touched the GPU: nothing here initialises HIP)
+    and relay their exit status.  A rank that dies takes the job down: the others are terminated by PID."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    deadline = time.time() + timeout_s
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+        if (rc != 0 or time.time() > deadline) and live:
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            live = []
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# runners: what a rank executes per step.  EngineRunner = the product (HIP engine through the C-ABI); StubRunner = a CPU stand-in
+# with the same interface so that tests/test_distributed.py can drive the REAL multi-rank code below over gloo without a GPU.
+class EngineRunner:
+    def __init__(self, args, cfg, W, local_rank, dtype, ids, mask):
+        import torch
+        from gliclass.c_amd import _lib
+        from gliclass.c_amd.engine import DTYPES
+        self.torch = torch
+        self.hipl = _lib.hip()
+        self.B, self.S = ids.shape
+        self.Cn = args.labels
+        self.h = self.hipl.glc_engine_create(C.byref(W.cfg), C.cast(W.tensors, C.POINTER(C.c_void_p)), W.n_tensors, local_rank, DTYPES[dtype])
+        if not self.h:
+            raise SystemExit("bench: engine create failed: " + self.hipl.glc_last_error().decode())
+        self.d_ids = self.hipl.glc_device_malloc(self.h, ids.nbytes)
+        self.d_mask = self.hipl.glc_device_malloc(self.h, mask.nbytes)
+        # logits live in a torch tensor so that the strong mode can hand them to RCCL without a copy
+        self.logits = torch.zeros((self.B, self.Cn), dtype=torch.float32, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        self.hipl.glc_memcpy_h2d(self.h, self.d_ids, ids.ctypes.data, ids.nbytes)
+        self.hipl.glc_memcpy_h2d(self.h, self.d_mask, mask.ctypes.data, mask.nbytes)
+
+    def step(self):
+        if self.hipl.glc_engine_forward_device(self.h, self.d_ids, self.d_mask, self.B, self.S, self.Cn, C.c_void_p(self.logits.data_ptr())) != 0:
+            raise RuntimeError(self.hipl.glc_last_error().decode())
+
+    def sync(self):
+        if self.hipl.glc_engine_sync(self.h) != 0:
+            raise RuntimeError(self.hipl.glc_last_error().decode())
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        self.sync()
+        self.hipl.glc_device_free(self.h, self.d_ids)
+        self.hipl.glc_device_free(self.h, self.d_mask)
+        self.hipl.glc_engine_destroy(self.h)
+        self.h = None
+
+
+class StubRunner:
+    """logits[b, j] = global row id * 16 + j — lets a CPU test check that the gather puts every row where it belongs."""
+    def __init__(self, args, row_lo, n_rows):
+        import torch
+        self.torch = torch
+        self.row_lo, self.B, self.Cn = row_lo, n_rows, args.labels
+        self.logits = torch.zeros((n_rows, self.Cn), dtype=torch.float32)
+        self.calls = 0
+
+    def step(self):
+        self.calls += 1
+        r = self.torch.arange(self.row_lo, self.row_lo + self.B, dtype=self.torch.float32)[:, None]
+        self.logits.copy_(r * 16 + self.torch.arange(self.Cn, dtype=self.torch.float32)[None, :])
+        time.sleep(0.002)
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def gather_logits(dist, runner, world, rank, global_rows, Cn):
+    """Strong mode, once per step: the [rows_g, C] logits of every rank -> rank 0's [B, C] (a < 10 KB, latency-bound
+    all-gather; the only collective on the data path).  Shards are padded to the largest one (B need not divide by G)."""
+    torch = runner.torch
+    if dist is None:
+        return runner.logits
+    cap = max(shard_rows(global_rows, world, r)[1] - shard_rows(global_rows, world, r)[0] for r in range(world))
+    mine = runner.logits
+    if mine.shape[0] < cap:
+        mine = torch.cat([mine, torch.zeros((cap - mine.shape[0], Cn), dtype=mine.dtype, device=mine.device)])
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine.contiguous())
+    if rank != 0:
+        return None
+    return torch.cat([parts[r][: shard_rows(global_rows, world, r)[1] - shard_rows(global_rows, world, r)[0]] for r in range(world)])
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, wptrs, S, C_labels, seqs, seqs8):
+    """The CPU oracle timed on this box's host cores: all the cores this job may use, then OMP_NUM_THREADS=8 — the reference's
+    NUM_THREADS (/root/reference/include/configs.h:7) — on a smaller sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     from gliclass.c_amd import synth
     ids, mask, _ = synth.make_inputs(cfg, seqs, S, C_labels, seed=1234)
     lib = oracle_c.lib()              # team sized to the CPUs this job may really use (affinity / cgroup quota): `cores` below
-    logits = np.zeros((seqs, C_labels), np.float32)
-    c_out = C.c_int(0)
     cc = oracle_c._cfg(cfg)
     ptrs = C.cast(wptrs, C.POINTER(C.c_void_p))
-    t0 = time.perf_counter()
-    rc = lib.glo_forward(C.byref(cc), ptrs, ids.ctypes.data, mask.ctypes.data, seqs, S, logits.ctypes.data, C_labels,
-                         C.byref(c_out), None, None)
-    dt = time.perf_counter() - t0
-    if rc != 0:
-        raise RuntimeError("oracle failed")
-    return dict(value=seqs / dt, unit="sequences/s", cores=int(lib.glo_num_threads()), kind="port",
-                sample=f"{seqs} sequence(s) of the same workload (S={S}, {C_labels} labels), fp32 C/OpenMP oracle "
-                       f"(CPU restatement, not ONNXRuntime), {dt:.1f} s"), logits, ids, mask
+    fwd = lib.glo_forward_decoder if cfg.backbone == 1 else lib.glo_forward
+
+    def run(n):
+        logits = np.zeros((n, C_labels), np.float32)
+        c_out = C.c_int(0)
+        a = [C.byref(cc), ptrs, ids.ctypes.data, mask.ctypes.data, n, S, logits.ctypes.data, C_labels, C.byref(c_out), None]
+        if cfg.backbone != 1:
+            a.append(None)
+        t0 = time.perf_counter()
+        rc = fwd(*a)
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("oracle failed")
+        return dt, logits
+    cores = int(lib.glo_num_threads())
+    dt, logits = run(seqs)
+    out = dict(value=seqs / dt, unit="sequences/s", cores=cores, kind="port", cpu_model=cpu_model_name(),
+               sample=f"{seqs} sequence(s) of the same workload (S={S}, {C_labels} labels), fp32 C/OpenMP oracle "
+                      f"(CPU restatement, not ONNXRuntime), {dt:.1f} s")
+    if seqs8 > 0 and cores > 8:
+        lib.glo_set_threads(8)
+        dt8, _ = run(min(seqs8, seqs))
+        lib.glo_set_threads(cores)
+        out["value_8_threads"] = min(seqs8, seqs) / dt8
+        out["sample_8_threads"] = f"{min(seqs8, seqs)} sequence(s), OMP_NUM_THREADS=8 (the reference's NUM_THREADS), {dt8:.1f} s"
+    return out, logits, ids, mask
+
+
+def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, config_key):
+    """Per-kernel-class HIP-event profile of 3 forwards on the engine's stream -> the `roofline` object."""
+    fl = kernel_flops(cfg, B, S)
+    hipl.glc_profile_enable(h, 1)
+    for _ in range(3):
+        step()
+        sync()
+    names = (C.c_char_p * 16)(); ms = (C.c_float * 16)(); cnt = (C.c_int * 16)()
+    k = hipl.glc_profile_read(h, names, ms, cnt, 16)
+    hipl.glc_profile_enable(h, 0)
+    prof = {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(k) if cnt[i] > 0}
+    total_ms = sum(v[0] for v in prof.values())
+    per = {}
+    for n, (tms, c) in prof.items():
+        avg = tms / c
+        e = dict(avg_ms=round(avg, 4), launches_per_fwd=c // 3, share=round(tms / total_ms, 4))
+        if n in fl:
+            e["tflops"] = round(fl[n] / (avg * 1e-3) / 1e12, 1)
+        per[n] = e
+    dom = max((n for n in per if n in fl), key=lambda n: per[n]["avg_ms"] * per[n]["launches_per_fwd"])
+    peak = PEAK_TFLOPS[dtype]
+    e2e = cfg.flops_per_seq(S, Cn) * seqs_per_s_one_gpu / 1e12
+    # FLOPs really executed per forward: the last layer runs Q / attention output / FFN only on the B*(1+C) rows the head reads
+    executed = e2e
+    if cfg.backbone != 1 and os.environ.get("GLICLASS_PRUNE_LAST", "1") != "0":
+        H, I, P = cfg.hidden, cfg.inter, 2 * cfg.att_span
+        full_last = S * (8.0 * H * H + 4.0 * H * I + 4.0 * S * H + 4.0 * P * H)
+        kept_last = S * 4.0 * H * H + (1 + Cn) * (4.0 * H * H + 4.0 * H * I + 4.0 * S * H + 4.0 * P * H)      # K, V for every row; the rest on 1+C rows
+        executed = (cfg.flops_per_seq(S, Cn) - full_last + kept_last) * seqs_per_s_one_gpu / 1e12
+    traffic, traffic_src = None, None
+    try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be collected live)
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(dtype)
+        if ent and ent.get("config") == config_key and dom in ent.get("kernels", {}):
+            traffic = ent["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/traffic.json (" + ent.get("source", "?") + ")"
+    except Exception:
+        pass
+    mpp = MFMA_PER_PRODUCT[dtype]
+    return dict(bound="mfma", kernel=dom, achieved=per[dom]["tflops"], peak=peak, unit="TFLOP/s",
+                frac=round(per[dom]["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_src,
+                flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
+                mfma_per_product=mpp, executed_mfma_frac=round(per[dom]["tflops"] * mpp / peak, 4),
+                e2e_achieved=round(e2e, 1), e2e_peak=peak, e2e_frac=round(e2e / peak, 4),
+                executed_flops_frac=round(executed / peak, 4), per_kernel=per)
+
+
+def prob_err(a, b):
+    return float(np.abs(1 / (1 + np.exp(-a.astype(np.float64))) - 1 / (1 + np.exp(-b.astype(np.float64)))).max())
 
 
 def main():
@@ -91,20 +314,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default=os.environ.get("GLICLASS_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
+    ap.add_argument("--dtype", default=os.environ.get("GLICLASS_DTYPE", "f32"), choices=["f32", "f16", "bf16"],
+                    help="arithmetic mode of the headline number (default: the product's default, f32 = split-f16 MFMA products)")
+    ap.add_argument("--throughput-dtype", default="f16", choices=["f16", "bf16", "none"], help="opt-in 16-bit mode measured beside the headline (N=1)")
     ap.add_argument("--config", default="base")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--labels", type=int, default=8)
-    ap.add_argument("--cpu-seqs", type=int, default=16, help="sequences timed on the CPU baseline, N=1 only (0 = skip); 16 = 10-20 s on a 16-CPU share")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--cpu-seqs", type=int, default=12, help="sequences timed on the CPU baseline, N=1 only (0 = skip); 12 = about 10 s on a 16-CPU share")
+    ap.add_argument("--cpu-seqs-8", type=int, default=6, help="sequences of the OMP_NUM_THREADS=8 leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)        # CPU rehearsal of the multi-rank path (tests): gloo + StubRunner
     args = ap.parse_args()
 
+    # ---- the N ranks: from the launcher's environment, or started here ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.stub:
+            import torch                      # device_count() does not initialise HIP on this image
+            nd = torch.cuda.device_count()
+            if nd < args.gpus:
+                raise SystemExit(f"bench: --gpus {args.gpus} but only {nd} GPU(s) visible")
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     # host threads: the CPUs this job may really use (affinity / cgroup quota, not the 256 a GPU box shows), shared between the
     # N ranks of one node, which generate their synthetic weights at the same time
@@ -116,169 +352,174 @@ def main():
     if world > 1 or os.environ.get("GLC_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist_
         dist = dist_
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        if args.stub:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            if torch.cuda.device_count() <= local_rank:
+                raise SystemExit(f"bench: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        world = dist.get_world_size()          # n_gpus is what really joined the group
 
-    from gliclass.c_amd import _lib, synth
     from gliclass.c_amd.config import CONFIGS
-    from gliclass.c_amd.engine import DTYPES
-
     cfg = CONFIGS[args.config]
-    B, S, Cn = args.batch, args.seq, args.labels
-    hipl, modl = _lib.hip(), _lib.model()
-    if hipl.glc_device_count() <= local_rank:
-        raise SystemExit("bench: no HIP device for this rank (the engine has no CPU path)")
+    S, Cn = args.seq, args.labels
+    if args.scaling == "strong":
+        lo, hi = shard_rows(args.batch, world, rank)
+        global_rows = args.batch
+    else:
+        lo, hi = 0, args.batch
+        global_rows = args.batch * world
+    B = hi - lo
+    if B <= 0:
+        raise SystemExit(f"bench: rank {rank} got no rows (--batch {args.batch} over {world} ranks)")
 
-    # weights: deterministic synthetic (no checkpoints offline), generated by the C host layer
-    W = _lib.Weights()
-    if modl.glc_weights_load(f"synthetic:{args.config}:42".encode(), C.byref(W)) != 0:
-        raise SystemExit("bench: weight generation failed")
-    h = hipl.glc_engine_create(C.byref(W.cfg), C.cast(W.tensors, C.POINTER(C.c_void_p)), W.n_tensors, local_rank, DTYPES[args.dtype])
-    if not h:
-        raise SystemExit("bench: engine create failed: " + hipl.glc_last_error().decode())
+    W = hipl = modl = None
+    if args.stub:
+        runner = StubRunner(args, lo, B)
+    else:
+        from gliclass.c_amd import _lib, synth
+        hipl, modl = _lib.hip(), _lib.model()
+        if hipl.glc_device_count() <= local_rank:
+            raise SystemExit("bench: no HIP device for this rank (the engine has no CPU path)")
+        # weights: deterministic synthetic (no checkpoints offline), generated by the C host layer
+        W = _lib.Weights()
+        if modl.glc_weights_load(f"synthetic:{args.config}:42".encode(), C.byref(W)) != 0:
+            raise SystemExit("bench: weight generation failed")
+        if args.scaling == "strong":          # one global batch, this rank's contiguous rows of it
+            gids, gmask, _ = synth.make_inputs(cfg, args.batch, S, Cn, seed=1234)
+            ids, mask = np.ascontiguousarray(gids[lo:hi]), np.ascontiguousarray(gmask[lo:hi])
+        else:
+            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=1234 + rank)
+        runner = EngineRunner(args, cfg, W, local_rank, args.dtype, ids, mask)
 
-    ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=1234 + rank)
-    d_ids = hipl.glc_device_malloc(h, ids.nbytes)
-    d_mask = hipl.glc_device_malloc(h, mask.nbytes)
-    d_logits = hipl.glc_device_malloc(h, B * Cn * 4)
-    hipl.glc_memcpy_h2d(h, d_ids, ids.ctypes.data, ids.nbytes)
-    hipl.glc_memcpy_h2d(h, d_mask, mask.ctypes.data, mask.nbytes)
+    gathered = [None]
 
     def step():
-        if hipl.glc_engine_forward_device(h, d_ids, d_mask, B, S, Cn, d_logits) != 0:
-            raise RuntimeError(hipl.glc_last_error().decode())
-
-    def sync():
-        if hipl.glc_engine_sync(h) != 0:
-            raise RuntimeError(hipl.glc_last_error().decode())
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        runner.step()
+        if args.scaling == "strong" and dist is not None:
+            runner.sync()                                  # the logits must be complete before RCCL reads them
+            gathered[0] = gather_logits(dist, runner, world, rank, global_rows, Cn)
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if not args.stub else dist.barrier()
 
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.stub else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed = time_steps(step, sync, barrier, max_over_ranks, args.steps, args.warmup)
-    seqs_per_s = world * B * args.steps / elapsed
+    elapsed = time_steps(step, runner.sync, barrier, max_over_ranks, args.steps, args.warmup)
+    seqs_per_s = global_rows * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
-    # HIP-event cross-check of the same loop on this rank's stream
-    hipl.glc_timer_start(h)
-    for _ in range(args.steps):
-        step()
-    ev_ms = float(hipl.glc_timer_stop_ms(h)) / args.steps
-
     out = None
-    if rank == 0:
-        logits = np.zeros((B, Cn), np.float32)
-        hipl.glc_memcpy_d2h(h, logits.ctypes.data, d_logits, logits.nbytes)
-        fl = kernel_flops(cfg, B, S)
-        roof = None
-        if not args.no_profile:
-            hipl.glc_profile_enable(h, 1)
-            for _ in range(3):
-                step()
-                sync()
-            names = (C.c_char_p * 16)(); ms = (C.c_float * 16)(); cnt = (C.c_int * 16)()
-            k = hipl.glc_profile_read(h, names, ms, cnt, 16)
-            hipl.glc_profile_enable(h, 0)
-            prof = {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(k) if cnt[i] > 0}
-            total_ms = sum(v[0] for v in prof.values())
-            per = {}
-            for n, (tms, c) in prof.items():
-                avg = tms / c
-                e = dict(avg_ms=round(avg, 4), launches_per_fwd=c // 3, share=round(tms / total_ms, 4))
-                if n in fl:
-                    e["tflops"] = round(fl[n] / (avg * 1e-3) / 1e12, 1)
-                per[n] = e
-            dom = max((n for n in per if n in fl), key=lambda n: per[n]["avg_ms"] * per[n]["launches_per_fwd"])
-            peak = PEAK_TFLOPS[args.dtype]
-            e2e = cfg.flops_per_seq(S, Cn) * seqs_per_s / world / 1e12
-            e2e_peak = peak
-            if args.dtype == "f32" and os.environ.get("GLICLASS_F32_GEMM") != "native":
-                # parity-grade mode: the dense projections run as three f16 MFMAs per product (split operands), i.e. against
-                # 2500/3 TF of fp32-equivalent work; attention stays on the fp32 MFMA (157.3 TF).  Time-weighted mixed peak.
-                gem = sum(per[n]["avg_ms"] * per[n]["launches_per_fwd"] for n in per if n.startswith("gemm"))
-                tot = sum(per[n]["avg_ms"] * per[n]["launches_per_fwd"] for n in per)
-                e2e_peak = round(1.0 / ((gem / tot) / (PEAK_TFLOPS["f16"] / 3.0) + (1.0 - gem / tot) / peak), 1)
-                for n in per:
-                    if n.startswith("gemm"):
-                        per[n]["peak"] = round(PEAK_TFLOPS["f16"] / 3.0, 1)
-            traffic, traffic_src = None, None
-            try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (cannot be live)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if dom in tj.get("kernels", {}) and args.dtype == "f16" and (args.config, B, S) == ("base", 64, 1024):
-                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/traffic.json (" + tj.get("source", "?") + ")"
-            except Exception:
-                pass
-            roof = dict(bound="mfma", kernel=dom, achieved=per[dom]["tflops"], peak=peak, unit="TFLOP/s",
-                        frac=round(per[dom]["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_src,
-                        flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
-                        e2e_achieved=round(e2e, 1), e2e_peak=e2e_peak, e2e_frac=round(e2e / e2e_peak, 4), per_kernel=per)
-        cpu = None
-        if args.cpu_seqs > 0 and world == 1:
-            cpu, ref_logits, rids, rmask = cpu_baseline(cfg, W.tensors, W.n_tensors, S, Cn, args.cpu_seqs)
-            # parity spot-check of the timed configuration itself (same seed => first rows identical)
-            got = np.zeros((args.cpu_seqs, Cn), np.float32)
-            c_out = C.c_int(0)
-            hipl.glc_engine_forward(h, rids.ctypes.data, rmask.ctypes.data, args.cpu_seqs, S, got.ctypes.data, Cn, C.byref(c_out))
-            pe = np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref_logits.astype(np.float64)))).max()
-            cpu["gpu_vs_cpu_max_prob_err"] = float(pe)
-        out = {
-            "metric": "sequences/sec at batch=64 seq=1024, gliclass-base; %MFMA-peak; 1/2/4/8-GPU",
-            "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"gliclass-{args.config} (DeBERTa-v3 shape L={cfg.layers} H={cfg.hidden}), batch={B} seq={S} labels={Cn}, "
-                                   f"random-init weights (seed 42), full-length rows", "global_batch": B * world, "seq_len": S,
-                       "parallelism": f"batch-shard x{world} (one process per GPU, no data-path collective)"},
-            "hip_event_ms_per_step": round(ev_ms, 3),
-            "finite": bool(np.isfinite(logits).all()),
-        }
-        if roof:
-            out["roofline"] = roof
-        if cpu:
-            out["cpu_baseline"] = cpu
-        if cpu and world == 1 and args.dtype != "f32":
-            # The same workload in the parity-grade mode (fp32 data, split-f16 three-MFMA products): the 16-bit
-            # throughput modes sit above the 1e-3 bar on these random-weight models, this one sits far below it.  Reported beside
-            # the headline number, never instead of it.
-            h32 = hipl.glc_engine_create(C.byref(W.cfg), C.cast(W.tensors, C.POINTER(C.c_void_p)), W.n_tensors, local_rank, DTYPES["f32"])
-            if h32:
-                p_ids = hipl.glc_device_malloc(h32, ids.nbytes); p_mask = hipl.glc_device_malloc(h32, mask.nbytes)
-                p_log = hipl.glc_device_malloc(h32, B * Cn * 4)
-                hipl.glc_memcpy_h2d(h32, p_ids, ids.ctypes.data, ids.nbytes)
-                hipl.glc_memcpy_h2d(h32, p_mask, mask.ctypes.data, mask.nbytes)
-                nsteps = max(2, min(args.steps, 5))
-                hipl.glc_engine_forward_device(h32, p_ids, p_mask, B, S, Cn, p_log)
-                hipl.glc_engine_sync(h32)
-                hipl.glc_timer_start(h32)
-                for _ in range(nsteps):
-                    hipl.glc_engine_forward_device(h32, p_ids, p_mask, B, S, Cn, p_log)
-                pms = float(hipl.glc_timer_stop_ms(h32)) / nsteps
-                got = np.zeros((args.cpu_seqs, Cn), np.float32)
+    if args.stub:
+        if rank == 0:
+            full = gathered[0] if gathered[0] is not None else runner.logits
+            out = {"metric": "stub", "value": round(seqs_per_s, 2), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "scaling": args.scaling, "global_batch": global_rows, "rows_rank0": B, "step_calls_rank0": runner.calls,
+                   "gathered_rows": [int(v) for v in (full[:, 0] / 16).tolist()] if args.scaling == "strong" else None}
+    else:
+        h = runner.h
+        # HIP-event cross-check of the same loop on this rank's stream
+        hipl.glc_timer_start(h)
+        for _ in range(args.steps):
+            runner.step()
+        ev_ms = float(hipl.glc_timer_stop_ms(h)) / args.steps
+        gather_ms = None
+        if args.scaling == "strong" and dist is not None:        # the collective alone, HIP-event free (host clock, synchronous)
+            runner.sync()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                gather_logits(dist, runner, world, rank, global_rows, Cn)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - t0) / 20 * 1e3
+        if rank == 0:
+            logits = (gathered[0] if gathered[0] is not None else runner.logits).cpu().numpy()
+            key = f"{args.config}:{args.batch}:{S}"
+            roof = None
+            if not args.no_profile:
+                roof = profile_mode(hipl, h, runner.step, runner.sync, cfg, B, S, Cn, args.dtype, B / (ev_ms * 1e-3), key)
+            # boundary-inclusive step (SURVEY.md §8d protocol): host int64 ids/mask in, H2D, forward, D2H of the logits out
+            host_ms = None
+            if world == 1:
+                hl = np.zeros((B, Cn), np.float32)
                 c_out = C.c_int(0)
-                hipl.glc_engine_forward(h32, rids.ctypes.data, rmask.ctypes.data, args.cpu_seqs, S, got.ctypes.data, Cn, C.byref(c_out))
-                pe = np.abs(1 / (1 + np.exp(-got.astype(np.float64))) - 1 / (1 + np.exp(-ref_logits.astype(np.float64)))).max()
-                out["parity_grade_mode"] = {"dtype": "f32 data, split-f16 x3 MFMA products", "value": round(B / (pms * 1e-3), 2),
-                                            "unit": "sequences/s", "ms_per_step": round(pms, 3), "steps": nsteps,
-                                            "gpu_vs_cpu_max_prob_err": float(pe), "bar": 1e-3}
-                hipl.glc_device_free(h32, p_ids); hipl.glc_device_free(h32, p_mask); hipl.glc_device_free(h32, p_log)
-                hipl.glc_engine_destroy(h32)
-    sync()
-    hipl.glc_device_free(h, d_ids); hipl.glc_device_free(h, d_mask); hipl.glc_device_free(h, d_logits)
-    hipl.glc_engine_destroy(h)
-    modl.glc_weights_free(C.byref(W))
+                hipl.glc_engine_forward(h, ids.ctypes.data, mask.ctypes.data, B, S, hl.ctypes.data, Cn, C.byref(c_out))
+                t0 = time.perf_counter()
+                for _ in range(max(2, min(args.steps, 5))):
+                    hipl.glc_engine_forward(h, ids.ctypes.data, mask.ctypes.data, B, S, hl.ctypes.data, Cn, C.byref(c_out))
+                host_ms = (time.perf_counter() - t0) / max(2, min(args.steps, 5)) * 1e3
+            cpu = None
+            ref_logits = rids = rmask = None
+            if args.cpu_seqs > 0 and world == 1:
+                cpu, ref_logits, rids, rmask = cpu_baseline(cfg, W.tensors, S, Cn, min(args.cpu_seqs, B), args.cpu_seqs_8)
+                # parity check of the timed configuration itself: same seed => the oracle's rows are the first rows of the timed batch
+                n = rids.shape[0]
+                cpu["gpu_vs_cpu_max_prob_err"] = prob_err(logits[:n], ref_logits)
+                cpu["rows_compared"] = n
+            mode_txt = {"f32": "f32 data, split-f16 x3 MFMA products (the product's default mode)", "f16": "f16 MFMA operands (opt-in throughput mode)",
+                        "bf16": "bf16 MFMA operands (opt-in throughput mode)"}[args.dtype]
+            shape_txt = (f"gliclass-{args.config} (DeBERTa-v3 shape L={cfg.layers} H={cfg.hidden})" if cfg.backbone != 1 else
+                         f"gliclass-{args.config} (decoder backbone L={cfg.layers} H={cfg.hidden}, {cfg.heads}q/{cfg.kv_heads}kv x {cfg.head_dim})")
+            out = {
+                "metric": "sequences/sec at batch=64 seq=1024, gliclass-base; %MFMA-peak",
+                "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                "dtype": args.dtype, "mode": mode_txt, "data": "synthetic",
+                "config": {"workload": f"{shape_txt}, batch={args.batch} seq={S} labels={Cn}, random-init weights (seed 42), full-length rows",
+                           "global_batch": global_rows, "seq_len": S,
+                           "parallelism": (f"batch-shard x{world}: one process per GPU, every rank a full batch, no data-path collective" if args.scaling == "weak" else
+                                           f"batch-shard x{world}: one global batch split contiguously ({B} rows on rank 0), logits all-gathered to rank 0 every step (RCCL)")},
+                "hip_event_ms_per_step": round(ev_ms, 3),
+                "finite": bool(np.isfinite(logits).all()),
+            }
+            if host_ms is not None:
+                out["host_buffer_ms_per_step"] = round(host_ms, 3)     # H2D of ids/mask + forward + D2H of logits (glc_engine_forward)
+            if gather_ms is not None:
+                out["gather_ms"] = round(gather_ms, 4)
+            if roof:
+                out["roofline"] = roof
+            if cpu:
+                out["cpu_baseline"] = cpu
+                out["parity_ok"] = bool(cpu["gpu_vs_cpu_max_prob_err"] <= BAR)
+                out["parity_bar"] = BAR
+            tdt = args.throughput_dtype
+            if cpu and world == 1 and tdt != "none" and tdt != args.dtype:
+                # The opt-in 16-bit throughput mode on the same workload: reported beside the headline number, never instead of
+                # it — its operand rounding alone can exceed the 1e-3 bar on these random-weight models.
+                runner.close()
+                r2 = EngineRunner(args, cfg, W, local_rank, tdt, ids, mask)
+                for _ in range(2):
+                    r2.step()
+                r2.sync()
+                nsteps = max(2, min(args.steps, 10))
+                hipl.glc_timer_start(r2.h)
+                for _ in range(nsteps):
+                    r2.step()
+                pms = float(hipl.glc_timer_stop_ms(r2.h)) / nsteps
+                r2.sync()
+                lg2 = r2.logits.cpu().numpy()
+                pe = prob_err(lg2[: rids.shape[0]], ref_logits)
+                tm = {"dtype": tdt, "value": round(B / (pms * 1e-3), 2), "unit": "sequences/s", "ms_per_step": round(pms, 3), "steps": nsteps,
+                      "gpu_vs_cpu_max_prob_err": pe, "parity_ok": bool(pe <= BAR), "bar": BAR, "opt_in": f"GLICLASS_DTYPE={tdt}"}
+                if not args.no_profile:
+                    tm["roofline"] = profile_mode(hipl, r2.h, r2.step, r2.sync, cfg, B, S, Cn, tdt, B / (pms * 1e-3), key)
+                out["throughput_mode"] = tm
+                r2.close()
+                runner = None
+    if runner is not None:
+        runner.close()
+    if modl is not None:
+        modl.glc_weights_free(C.byref(W))
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -99,16 +99,18 @@ int main(int argc, char* argv[]) {
     OrtValue** output_tensors = (OrtValue**)calloc(num_batches ? num_batches : 1, sizeof(OrtValue*));
 
     const char* pl = getenv("GLICLASS_PIPELINE");
+    size_t failed_batches = 0;
     double start_time = omp_get_wtime();
     if (pl && pl[0] == '0') {                     /* the reference's three phases, a barrier after each (main.c:116-155) */
         parallel_preprocess(texts, labels, num_labels, num_texts, same_labels, prompt_first, tokenizer_handler,
                             input_ids_tensors, attention_mask_tensors);
         parallel_inference(session, input_ids_tensors, attention_mask_tensors, num_batches, output_tensors);
+        for (size_t i = 0; i < num_batches; i++) failed_batches += output_tensors[i] == NULL;    /* counted before post releases them */
         parallel_postprocess(output_tensors, num_batches, num_texts, texts, labels, num_labels, same_labels, num_labels_size,
                              classification_type);
     } else {                                      /* default: the same stages pipelined per batch, results printed in batch order */
-        parallel_classify(session, tokenizer_handler, texts, labels, num_labels, num_texts, same_labels, num_labels_size,
-                          prompt_first, classification_type);
+        failed_batches = parallel_classify(session, tokenizer_handler, texts, labels, num_labels, num_texts, same_labels, num_labels_size,
+                                           prompt_first, classification_type);
     }
     double end_time = omp_get_wtime();
     printf("Execution time: %f seconds\n", end_time - start_time);
@@ -124,5 +126,9 @@ int main(int argc, char* argv[]) {
     g_ort->ReleaseSession(session);
     g_ort->ReleaseEnv(env);
     free_parsed_data(texts, num_texts, labels, num_labels, same_labels, classification_type);
+    if (failed_batches) {
+        fprintf(stderr, "Error: %zu of %zu batches failed\n", failed_batches, num_batches);
+        return 2;
+    }
     return 0;
 }

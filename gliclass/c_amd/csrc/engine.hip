@@ -756,6 +756,16 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
     if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
     HIPCHK(hipStreamSynchronize(e->stream), -1);
     if (e->profile) prof_collect(e);
+    // Every matrix product runs on f16 / bf16 MFMA operands (the fp32 mode as split-f16 pairs), so an activation beyond the operand
+    // range (|x| > 65504 for f16) turns into inf / NaN silently.  A result the reference's fp32 graph would not produce must not be
+    // returned as if it were one: fail the call.  (fp32 mode: GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native run the fp32 MFMAs.)
+    for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n; ++i)
+        if (!isfinite(logits[i])) {
+            set_err("forward: non-finite logit (row " + std::to_string(i / c_alloc) + "): an activation left the range of the " +
+                    (e->dtype == GLC_BF16 ? "bf16" : "f16") + " MFMA operands" +
+                    (e->dtype == GLC_F32 ? "; set GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native for the fp32-MFMA kernels" : "; use GLICLASS_DTYPE=f32 or bf16"));
+            return -1;
+        }
     return 0;
 }
 

@@ -280,13 +280,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int kspl
 int splitk_parts(int epi, const GemmArgs& a, int nk) {
     static const int mode = getenv("GLC_GEMM_SPLITK") ? atoi(getenv("GLC_GEMM_SPLITK")) : 1;        // developer A/B switch (0 = off)
     if (!mode || epi == EPI_QKV || !a.ws || nk < 8) return 1;
-    static std::atomic<int> ncu_cache{0};
-    int ncu = ncu_cache.load(std::memory_order_relaxed);
-    if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        ncu_cache.store(ncu, std::memory_order_relaxed);
-    }
+    const int ncu = glc_device_cus();
     const long long tiles = (long long)(a.N / BN) * (a.Mpad / BM);
     if (tiles * 2 > ncu) return 1;
     int parts = (int)(ncu / tiles);                       // aim at about one workgroup per CU

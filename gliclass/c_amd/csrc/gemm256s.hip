@@ -353,13 +353,7 @@ const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmAr
 bool glc_gemm_small_m(const GemmArgs& a) {
     static const int mode = getenv("GLC_GEMM_SMALL_M") ? atoi(getenv("GLC_GEMM_SMALL_M")) : 1;     // developer A/B switch (0 = off)
     if (!mode) return false;
-    static std::atomic<int> ncu_cache{0};
-    int ncu = ncu_cache.load(std::memory_order_relaxed);
-    if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        ncu_cache.store(ncu, std::memory_order_relaxed);
-    }
+    const int ncu = glc_device_cus();
     return (long long)(a.Mpad / TM) * (a.N / TN) * 2 < ncu;
 }
 

@@ -88,6 +88,18 @@ struct AttnArgs {
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
 
 #include <atomic>
+// CU count of the CURRENT device, cached per device ordinal (a session may span GPUs of different sizes)
+inline int glc_device_cus() {
+    static std::atomic<int> cache[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 // Kernels that need more than 64 KiB of dynamic LDS raise the per-function limit once per device.
 template <typename F> inline bool glc_raise_lds_limit(F* kernel, int bytes, std::atomic<unsigned>& done) {
     int dev = 0;

@@ -26,7 +26,7 @@ def delta_table(S, bucket_size=256, max_position=512):
 
 
 class Engine:
-    def __init__(self, cfg: GLiClassConfig, tensors, dtype="f16", device=0):
+    def __init__(self, cfg: GLiClassConfig, tensors, dtype="f32", device=0):
         self.L = _lib.hip()
         self.cfg = cfg
         self.dtype = dtype
@@ -39,7 +39,7 @@ class Engine:
             raise RuntimeError("glc_engine_create: " + self.L.glc_last_error().decode())
 
     @classmethod
-    def from_spec(cls, cfg: GLiClassConfig, spec: str, dtype="f16", device=0):
+    def from_spec(cls, cfg: GLiClassConfig, spec: str, dtype="f32", device=0):
         """Engine from a model path / "synthetic:<config>[:seed]" through the C weight source (glc_weights_load, the same
         code create_ort_session uses) — no Python-side copy of the tensors, which matters for the 1.5 B-parameter config."""
         M = _lib.model()

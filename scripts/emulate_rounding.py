@@ -1,28 +1,37 @@
-"""Developer evidence (CPU, torch): emulates the engine's f16 rounding points one group at a time on the small
-config and reports the logit error each group alone causes vs the fp32 C oracle.  Output committed as
-profiles/r01_f16_rounding_ablation.txt; discussed in DESIGN.md §2."""
-import sys, math; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
+"""Developer evidence (CPU, torch): emulates the engine's operand-rounding points, one group at a time or in mixes, and
+reports the per-label PROBABILITY error each choice causes against the fp32 C oracle.  Round 2: run on the headline shape
+(base, S=1024) with n-bit rounding, so that mixed modes (some operand groups at 11 bits = f16, others at >= 13 bits = f16 +
+low-precision correction term, or split-f16 = ~21 bits) can be priced before they are built.
+    python scripts/emulate_rounding.py [config] [B] [S] [labels]      -> profiles/r02_rounding_budget_<config>.txt
+Groups: W weights, X/H1 GEMM input activations (LayerNorm outputs), QK / V QKV outputs, P softmax probabilities, CTX attention
+output, FF GELU output, EMB embedding table, POS relative-position operands (PQ / PK)."""
+import sys, math, time; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle')
 import numpy as np, torch
 from gliclass.c_amd.config import CONFIGS
 from gliclass.c_amd import weights, synth
 import oracle_c
 torch.set_num_threads(8)
-def run(cfg, w, ids, mask, rdf, tags, resid32=True):
-    rd0 = rdf
-    def mk(tag):
-        return (lambda x: rd0(x)) if (tags is None or tag in tags) else (lambda x: x)
-    rdW, rdX, rdQK, rdV, rdP, rdC, rdH1, rdFF, rdE, rdPos = [mk(t) for t in ('W','X','QK','V','P','CTX','H1','FF','EMB','POS')]
-    """torch emulation of the engine's rounding points. rd(x): round to operand dtype. resid32: keep residual stream fp32."""
+GROUPS = ('W','X','H1','QK','V','P','CTX','FF','EMB','POS')
+def rbits(n):
+    if n is None or n >= 24: return lambda x: x
+    if n == 11: return lambda x: x.half().float()
+    def f(x):
+        m, e = torch.frexp(x)
+        return torch.ldexp(torch.round(m * (1 << n)) / (1 << n), e)
+    return f
+def run(cfg, w, ids, mask, bits):
+    """bits: dict group -> mantissa bits (absent = exact fp32)"""
+    rd = {g: rbits(bits.get(g)) for g in GROUPS}
+    rdW, rdX, rdQK, rdV, rdP, rdC, rdH1, rdFF, rdE, rdPos = [rd[t] for t in ('W','X','QK','V','P','CTX','H1','FF','EMB','POS')]
     W = {k: torch.from_numpy(v) for k, v in w.items()}
     B, S = ids.shape; H, nh, d = cfg.hidden, cfg.heads, 64
     ids_t = torch.from_numpy(ids); m = torch.from_numpy(mask).float()
     ln = lambda x, p: torch.nn.functional.layer_norm(x, (H,), W[p+'.weight'], W[p+'.bias'], cfg.ln_eps)
-    rs = (lambda x: x)
     X = ln(rdE(W['embeddings.word_embeddings.weight'])[ids_t], 'embeddings.LayerNorm') * m[..., None]
-    Xr = rs(X); Xo = rdX(X)
+    Xr = X; Xo = rdX(X)
     R = ln(W['encoder.rel_embeddings.weight'], 'encoder.LayerNorm')
     dtab = torch.from_numpy(oracle_c.delta_table(S).astype(np.int64))
-    qi = torch.arange(S); idx = dtab[(qi[:, None] - qi[None, :]) + S - 1]        # [S,S]
+    qi = torch.arange(S); idx = dtab[(qi[:, None] - qi[None, :]) + S - 1]
     scale = math.sqrt(3 * d)
     kb = (1 - m)[:, None, None, :] * -1e30
     for l in range(cfg.layers):
@@ -32,34 +41,55 @@ def run(cfg, w, ids, mask, rdf, tags, resid32=True):
         Q = rdQK(Xo @ wq.T + bq).view(B, S, nh, d).transpose(1, 2)
         K = rdQK(lin(Xo, 'attention.self.key_proj')).view(B, S, nh, d).transpose(1, 2)
         V = rdV(lin(Xo, 'attention.self.value_proj')).view(B, S, nh, d).transpose(1, 2)
-        Ro = rdPos(R)
-        PQ = rdPos(Ro @ wq.T + bq).view(-1, nh, d).transpose(0, 1)     # [nh,P,d]
-        PK = rdPos(Ro @ rdW(W[p+'attention.self.key_proj.weight']).T + W[p+'attention.self.key_proj.bias']).view(-1, nh, d).transpose(0, 1)
-        s = Q @ K.transpose(-1, -2)
-        c2p = torch.gather(Q @ PK.transpose(-1, -2)[None], -1, idx[None, None].expand(B, nh, S, S))
-        p2c = torch.gather(K @ PQ.transpose(-1, -2)[None], -1, idx.T[None, None].expand(B, nh, S, S)).transpose(-1, -2)
-        pr = rdP(torch.softmax(s + c2p + p2c + kb, -1))
-        ctx = rdC((pr @ V).transpose(1, 2).reshape(B, S, H))
-        T1 = rs(lin(ctx, 'attention.output.dense') + Xr)
-        H1 = ln(T1, p+'attention.output.LayerNorm'); H1r = rs(H1); H1o = rdH1(H1)
+        PQ = rdPos(R @ wq.T + bq).view(-1, nh, d).transpose(0, 1)
+        PK = rdPos(R @ rdW(W[p+'attention.self.key_proj.weight']).T + W[p+'attention.self.key_proj.bias']).view(-1, nh, d).transpose(0, 1)
+        out = torch.empty(B, nh, S, d)
+        for b in range(B):                                   # per sequence: bounds the [nh,S,S] temporaries
+            s = Q[b] @ K[b].transpose(-1, -2)
+            s += torch.gather(Q[b] @ PK.transpose(-1, -2), -1, idx[None].expand(nh, S, S))
+            s += torch.gather(K[b] @ PQ.transpose(-1, -2), -1, idx.T[None].expand(nh, S, S)).transpose(-1, -2)
+            out[b] = rdP(torch.softmax(s + kb[b], -1)) @ V[b]
+        ctx = rdC(out.transpose(1, 2).reshape(B, S, H))
+        T1 = lin(ctx, 'attention.output.dense') + Xr
+        H1 = ln(T1, p+'attention.output.LayerNorm'); H1o = rdH1(H1)
         FF = rdFF(torch.nn.functional.gelu(lin(H1o, 'intermediate.dense')))
-        T2 = rs(lin(FF, 'output.dense') + H1r)
-        X = ln(T2, p+'output.LayerNorm'); Xr = rs(X); Xo = rdX(X)
-    hid = Xr
+        T2 = lin(FF, 'output.dense') + H1
+        X = ln(T2, p+'output.LayerNorm'); Xr = X; Xo = rdX(X)
     cm = ids_t == cfg.class_token_index
     C = int(cm.sum(1).max())
     def proj(x, n): return torch.nn.functional.gelu(x @ W[n+'.linear_1.weight'].T + W[n+'.linear_1.bias']) @ W[n+'.linear_2.weight'].T + W[n+'.linear_2.bias']
-    out = torch.zeros(B, C)
+    o = torch.zeros(B, C)
     for b in range(B):
         pos = torch.nonzero(cm[b]).flatten()
-        out[b, :len(pos)] = proj(hid[b, pos], 'classes_projector') @ proj(hid[b, 0], 'text_projector')
-    return out.numpy()
+        o[b, :len(pos)] = proj(Xr[b, pos], 'classes_projector') @ proj(Xr[b, 0], 'text_projector')
+    return o.numpy()
 sig = lambda x: 1/(1+np.exp(-x.astype(np.float64)))
-cfg = CONFIGS["small"]; w = weights.make_weights(cfg, 42)
-ids, mask, _ = synth.make_inputs(cfg, 4, 128, 4, seed=77, ragged=True)
-ref = oracle_c.forward(cfg, w, ids, mask)
-f16 = lambda x: x.half().float()
-with torch.no_grad():
-    for tags in (None, ('W',), ('X','H1'), ('QK',), ('V',), ('P',), ('CTX',), ('FF',), ('EMB',), ('POS',), ('W','X','H1','FF','CTX','V','EMB'), ('QK','POS','P')):
-        lg = run(cfg, w, ids, mask, f16, tags)
-        print(f"round only {str(tags):48s} max logit err {np.abs(lg-ref).max():.2e}  rms {np.sqrt(((lg-ref)**2).mean()):.2e}", flush=True)
+if __name__ == "__main__":
+    cname = sys.argv[1] if len(sys.argv) > 1 else "base"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    C = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    cfg = CONFIGS[cname]; w = weights.make_weights(cfg, 42)
+    ids, mask, _ = synth.make_inputs(cfg, B, S, C, seed=1234, ragged=False)
+    with torch.no_grad():
+        t0 = time.time(); ref = run(cfg, w, ids, mask, {}); t1 = time.time() - t0
+        pref = sig(ref)
+        print(f"# {cname} B={B} S={S} labels={C}: torch fp32 forward {t1:.1f} s; {B*C} probabilities per line", flush=True)
+        allg = lambda n: {g: n for g in GROUPS}
+        cases = [("all groups @11 (f16 everywhere)", allg(11))]
+        cases += [(f"only {g} @11", {g: 11}) for g in GROUPS]
+        cases += [("all @12", allg(12)), ("all @13", allg(13)), ("all @14", allg(14))]
+        mix = lambda hi, n: {g: (n if g in hi else 11) for g in GROUPS}
+        cases += [
+            ("W@21 rest @11 (weights split)", mix(('W',), 21)),
+            ("W,EMB@21 rest @11", mix(('W','EMB'), 21)),
+            ("W,EMB,POS,QK@21 rest @11", mix(('W','EMB','POS','QK'), 21)),
+            ("W,X,H1,FF,CTX,EMB@21 (GEMM operands) rest @11", mix(('W','X','H1','FF','CTX','EMB'), 21)),
+            ("QK,POS,P,V@21 (attention operands) rest @11", mix(('QK','POS','P','V'), 21)),
+            ("all@14 but FF,W(ffn)... n/a", None),
+        ]
+        for name, bits in cases:
+            if bits is None: continue
+            lg = run(cfg, w, ids, mask, bits)
+            pe = np.abs(sig(lg) - pref)
+            print(f"{name:52s} prob err max {pe.max():.2e} rms {np.sqrt((pe**2).mean()):.2e}   logit err max {np.abs(lg-ref).max():.2e} rms {np.sqrt(((lg-ref)**2).mean()):.2e}", flush=True)

@@ -174,3 +174,7 @@ def test_multi_engine_session_on_one_gpu(workdir):
     one = run("0", "1")
     assert run("0,0", "1") == one                          # pipelined: ordered retirement -> identical output
     assert sorted(run("0,0,0", "0")) == sorted(one)        # three phases (parallel_inference: one host thread per engine)
+    from gliclass.c_amd import _lib
+    if _lib.hip().glc_device_count() >= 2:                 # two DISTINCT devices when the box has them
+        assert run("0,1", "1") == one
+        assert sorted(run("0,1", "0")) == sorted(one)

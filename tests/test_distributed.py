@@ -83,3 +83,51 @@ def test_kernel_flops_sum_to_survey_formula():
     total = cfg.layers * per_layer + 64 * 8 * cfg.hidden ** 2 * (1 + 8)
     assert abs(total - 64 * cfg.flops_per_seq(1024, 8)) / total < 1e-12
     assert abs(cfg.flops_per_seq(1024, 8) / 1e9 - 231.95) < 0.05          # 231.95 GFLOP / sequence
+
+
+def _run_bench_stub(*flags):
+    """`python bench.py --gpus N --stub ...` with NO torch.distributed environment: bench.py itself starts the N ranks (the path the
+    driver's `python bench.py --gpus N` takes), joins them over gloo and runs the real partition / timing / gather code with a CPU
+    stand-in for the engine step."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", *flags], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks_strong_scaling():
+    """Strong mode: one global batch of 13 rows over 3 ranks (uneven shards 4/4/5), logits gathered to rank 0 every step."""
+    out = _run_bench_stub("--gpus", "3", "--scaling", "strong", "--batch", "13", "--labels", "4", "--steps", "5", "--warmup", "2")
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong" and out["global_batch"] == 13
+    assert out["rows_rank0"] == 4 and out["step_calls_rank0"] == 7
+    assert out["gathered_rows"] == list(range(13))          # every row exactly once, in order, on rank 0
+    assert out["value"] > 0
+
+
+def test_bench_spawns_its_own_ranks_weak_scaling():
+    out = _run_bench_stub("--gpus", "2", "--scaling", "weak", "--batch", "6", "--labels", "2", "--steps", "4", "--warmup", "1")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["global_batch"] == 12 and out["rows_rank0"] == 6
+    assert out["step_calls_rank0"] == 5
+
+
+def test_bench_refuses_more_ranks_than_rows_and_relays_failure():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "3", "--scaling", "strong", "--batch", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "got no rows" in r.stderr
+
+
+def test_bench_without_gpus_fails_loudly():
+    """No GPU in this container: the real (non-stub) multi-rank launch must refuse before starting any rank."""
+    import subprocess
+    import torch as _t
+    if _t.cuda.device_count() >= 2:
+        pytest.skip("GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

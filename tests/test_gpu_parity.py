@@ -478,3 +478,55 @@ def test_masked_class_token_is_refused(engines, weights_for):
         eng.forward(ids, mask)
     mask[0, pos] = 1
     assert np.isfinite(eng.forward(ids, mask)).all()
+
+
+def test_out_of_range_activation_fails_loudly(weights_for, tmp_path):
+    """Every matrix product runs on f16 MFMA operands (the default fp32 mode as split-f16 pairs), so an activation beyond 65504
+    becomes inf / NaN inside the kernels.  The host-buffer forward must refuse to return such logits ("a per-forward
+    overflow flag ... fail or fall back"); the fp32-MFMA kernels (GLICLASS_F32_GEMM/ATTN=native) handle the same model."""
+    import subprocess
+    import sys
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w0 = weights_for("tiny")
+    w = dict(w0)
+    w["embeddings.LayerNorm.weight"] = w0["embeddings.LayerNorm.weight"] * 3.0e5          # hidden states of the first layer ~ 3e5
+    ids, mask, _ = synth.make_inputs(cfg, 2, 80, 3, seed=3, ragged=True)
+    for dtype in ("f32", "f16"):
+        eng = Engine(cfg, w, dtype=dtype)
+        try:
+            with pytest.raises(RuntimeError, match="non-finite logit"):
+                eng.forward(ids, mask)
+        finally:
+            eng.close()
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{ROOT!r}]\n"
+        "from gliclass.c_amd import synth, weights\n"
+        "from gliclass.c_amd.config import CONFIGS\n"
+        "from gliclass.c_amd.engine import Engine\n"
+        "cfg = CONFIGS['tiny']; w = weights.make_weights(cfg, 42)\n"
+        "w['embeddings.LayerNorm.weight'] = w['embeddings.LayerNorm.weight'] * 3.0e5\n"
+        "ids, mask, _ = synth.make_inputs(cfg, 2, 80, 3, seed=3, ragged=True)\n"
+        "got = Engine(cfg, w, dtype='f32').forward(ids, mask)\n"
+        "print('FINITE', bool(np.isfinite(got).all()))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GLICLASS_F32_GEMM="native", GLICLASS_F32_ATTN="native"))
+    assert r.returncode == 0 and "FINITE True" in r.stdout, r.stderr[-2000:]
+
+
+def test_second_device_gives_identical_results(weights_for):
+    """An engine on GPU 1 (when the box has one) runs the same kernels as an engine on GPU 0: bit-identical logits — the
+    property the batch shard over GPUs rests on.  Also covers the per-device CU-count cache and LDS-limit mask."""
+    from gliclass.c_amd import _lib, synth
+    from gliclass.c_amd.engine import Engine
+    if _lib.hip().glc_device_count() < 2:
+        pytest.skip("one GPU visible")
+    cfg, w = weights_for("mini")
+    ids, mask, _ = synth.make_inputs(cfg, 9, 300, 4, seed=8, ragged=True)
+    for dtype in ("f32", "f16"):
+        e0, e1 = Engine(cfg, w, dtype=dtype, device=0), Engine(cfg, w, dtype=dtype, device=1)
+        try:
+            a, b = e0.forward(ids, mask), e1.forward(ids, mask)
+            assert np.array_equal(a, b), dtype
+        finally:
+            e0.close(); e1.close()

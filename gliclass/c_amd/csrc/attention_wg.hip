@@ -1,0 +1,416 @@
+// DeBERTa-v2/v3 disentangled self-attention, WORKGROUP-SHARED band kernel (round 2).  Same algebra, operand layouts and per-element
+// arithmetic as attn_band_kernel (attention.hip, whose header derives score = Q.K + Q.PK[delta(q-k)] + K.PQ[delta(q-k)] and the
+// Toeplitz-band form); what changes is who loads and who computes what:
+//
+//   * A workgroup = NW waves = NW consecutive 32-query tiles of ONE (batch, head).  Every key tile (K fragments 4 units, V^T 4 units)
+//     is fetched ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, 2 per wave and tile) into a
+//     3-slot LDS ring, one tile ahead, and read by all waves as ds_read_b128 fragments — the band kernel had every wave load
+//     its own copy through the L1 path (20 global_load_dwordx4 per wave and tile).
+//   * The p2c band is shared.  Wave w needs the relative-distance blocks b = w - t ("low") and b + 1 ("high") against key tile t;
+//     the high block of wave w IS the low block of wave w + 1.  So every wave computes only its low block (4 MFMAs instead of 8)
+//     into a workgroup-shared LDS image [32 keys][32 (NW + 1) distances], and the one block nobody owns (the high block of the last
+//     wave) is computed by wave t mod NW: NW + 1 blocks per key tile instead of 2 NW  (17 instead of 20 MFMAs per wave and tile
+//     at NW = 4, 16.5 at NW = 8; 12 are algorithmic).
+//   * The c2p term enters the S^T MFMA chain as its INITIAL ACCUMULATOR (gathered from the wave's ring at the top of the tile), so
+//     the score assembly is one add per element instead of two and the accumulator needs no zeroing.
+//   * Saturated key tiles (every q - k beyond the bucket clamp for ALL waves of the workgroup) run as before, per wave, on the shared
+//     K / V^T tiles.
+// Synchronisation per band tile: barrier X (every wave has finished gathering the previous tile's p2c image) -> p2c stores ->
+// barrier Y (image complete; every wave's DMA pieces of tile t + 1 have landed: s_waitcnt vmcnt(0) before it) -> gathers.  Saturated
+// tiles: one barrier.  The DMA runs up to two tiles ahead: tile t + 2 is requested right after barrier Y of tile t (top of a
+// saturated tile t) into slot (t + 2) % 3 = (t - 1) % 3, whose last readers are the P.V products of tile t - 1, which every wave has
+// retired (lgkmcnt(0)) before a barrier that the requesting wave has passed; its pieces are waited for (vmcnt(0)) before a barrier
+// of tile t + 1, i.e. a whole tile after the request, and first read at the top of tile t + 2.
+// NW = 4 (16-bit operands; 80 KiB LDS: two workgroups per CU, i.e. two independent waves per SIMD) or NW = 8 (split-f16 operands
+// of the fp32 mode, whose units are twice as large: 153 KiB, one workgroup of 8 waves per CU).
+#include <stdio.h>
+#include <stdlib.h>
+#include "glc_common.h"
+#include "glc_kernels.h"
+#include "glc_layout.h"
+
+namespace {
+
+constexpr float RESCALE_THR = 8.0f;   // log2 units (as attention.hip)
+constexpr int LROW = 68;              // floats per c2p ring row (2 blocks of 32 + 4 pad)
+
+template <bool SPLIT, typename T> struct WgFrag { typedef typename AFrag<T>::type type; };
+template <typename T> struct WgFrag<true, T> { typedef f16x8s type; };
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wg_barrier_lds() {          // all my LDS traffic retired, then the workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void wg_barrier_all() {          // ... and all my vector-memory traffic (LDS-DMA pieces included)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+
+// KVG = K / V^T fragments straight from global memory, per wave (no ring); the LDS it frees double-buffers the p2c image, which
+// removes barrier X: ONE workgroup barrier per band tile, none in saturated tiles.
+template <typename T, bool SPLIT, int NW, bool KVG>
+__global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
+    static_assert(!SPLIT || sizeof(T) == 4, "split operands live in the fp32 layouts");
+    static_assert(SPLIT || sizeof(T) == 2, "16-bit operands or split-f16 units");
+    typedef typename WgFrag<SPLIT, T>::type frag_t;
+    constexpr int UNITB = 512 * (int)sizeof(T);      // bytes of one fragment unit (64 lanes x 8 elements)
+    constexpr int TILEB = 4 * UNITB;                 // one K tile, or one V^T tile
+    constexpr int NPIECE = 2 * TILEB / 1024;         // 1-KiB DMA pieces per key tile (K then V^T): 8 or 16 = 2 per wave
+    static_assert(KVG || NPIECE == 2 * NW, "two DMA pieces per wave and tile");
+    constexpr int LROWP = 32 * (NW + 1) + 4;         // floats per p2c image row
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int Sp = a.Sp;
+
+    float* c2p_l = reinterpret_cast<float*>(smem_wg) + (size_t)wave * 32 * LROW;                     // this wave's ring [32 q][64 + 4]
+    float* p2c_img = reinterpret_cast<float*>(smem_wg) + (size_t)NW * 32 * LROW;                     // shared [32 keys][LROWP]
+    unsigned char* kv_ring = smem_wg + ((size_t)NW * 32 * LROW + 32 * LROWP) * sizeof(float);        // 3 x (K tile | V^T tile)
+
+    // XCD-aware decode of the 1-D grid: every query block of one (batch, head) gets the same id % 8 (shared L2 for its K / V^T)
+    const int nqb = (Sp + 32 * NW - 1) / (32 * NW);
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int bh = xcd + 8 * (jj / nqb);
+    const int Q0 = (jj % nqb) * 32 * NW;
+    if (bh >= a.B * a.nh) return;                       // workgroup-uniform
+    const int b = bh / a.nh, hh = bh - b * a.nh;
+    const int q0 = Q0 + 32 * wave;                      // this wave's query tile (may lie past Sp in the last block: computes, never stores)
+    const bool active = q0 < Sp;
+    const int q0m = active ? q0 : Sp - 32;              // memory-safe tile for the Q fragments of an inactive wave
+    if (a.tile_flag) {                                  // pruned last layer: skip workgroups without a selected query tile
+        bool any = false;
+        for (int w = 0; w < NW; ++w) { const int qw = Q0 + 32 * w; any = any || (qw < Sp && a.tile_flag[(size_t)b * (Sp >> 5) + (qw >> 5)]); }
+        if (!any) return;
+    }
+    const int klen = a.klen[b];
+    typedef T OutT;                                     // CTX rows carry the operand type (fp32 in the split mode)
+    OutT* outp = reinterpret_cast<OutT*>(a.CTX) + ((size_t)b * Sp + q0m + c) * a.H + hh * 64;
+    if (Q0 >= klen && Q0 > 0) {
+        // every query of this block lies past the row's last attended token (padding of a ragged batch): never read by an
+        // attended row; store zeros (finite) and leave
+        if (active) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { store4<OutT>(outp + 8 * g + 4 * h, 0.f, 0.f, 0.f, 0.f); store4<OutT>(outp + 32 + 8 * g + 4 * h, 0.f, 0.f, 0.f, 0.f); }
+        }
+        return;
+    }
+
+    const unsigned char* __restrict__ Qg = reinterpret_cast<const unsigned char*>(a.Qh) + ((size_t)bh * Sp + q0m) * 64 * sizeof(T) + lane * 8 * sizeof(T);
+    const unsigned char* __restrict__ Kg = reinterpret_cast<const unsigned char*>(a.Kh) + (size_t)bh * Sp * 64 * sizeof(T);
+    const unsigned char* __restrict__ Vg = reinterpret_cast<const unsigned char*>(a.Vt) + (size_t)bh * Sp * 64 * sizeof(T);
+    const unsigned char* __restrict__ PKg = reinterpret_cast<const unsigned char*>(a.PK) + ((size_t)hh * a.P * 64 + 32 * 8 * h) * sizeof(T);
+    const unsigned char* __restrict__ PQg = reinterpret_cast<const unsigned char*>(a.PQ) + ((size_t)hh * a.P * 64 + 32 * 8 * h) * sizeof(T);
+    const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
+
+    int nkt = (klen + 31) >> 5;                                    // key tiles beyond the last valid key add exactly 0
+    nkt = nkt < 1 ? 1 : (nkt > (Sp >> 5) ? (Sp >> 5) : nkt);
+    const int kfirst = a.kfirst[b];
+    const int foff = 8 * h;
+
+    // Position rows: otab entry (q - k) + Sp - 1 + 64 holds the byte offsets of row delta(q - k) in the PQ (x) / PK (y) layouts; 64
+    // clamped entries pad each end.  Row c of the LOW block of (query tile at qb, key tile t): rel = qb - 32 t - 31 + c.
+    const int otab_max = 2 * Sp - 2 + 128;
+    auto block_delta = [&](int qb, int t) -> int2 {
+        int idx = qb - 32 * t - 31 + c + Sp - 1 + 64;
+        idx = idx < 0 ? 0 : (idx > otab_max ? otab_max : idx);
+        return a.otab[idx];
+    };
+    auto load_rows = [&](const unsigned char* base, int off, frag_t (&f)[4]) {       // 4 fragment units of gathered table rows
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + off + s * UNITB);
+    };
+    auto k_tile = [&](int t, frag_t (&f)[4]) {                  // the 4 fragment units of key tile t: from the ring, or (KVG) from global
+        const unsigned char* tile = KVG ? Kg + (size_t)t * TILEB : kv_ring + (size_t)(t % 3) * 2 * TILEB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(tile + s * UNITB + lane * (UNITB / 64));
+    };
+    auto band_store = [&](float* dst, const f32x16& v) {           // 4 consecutive rr per register group
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = (f32x4){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    };
+    // LDS-DMA of key tile t into ring slot t % 3: piece p = 2 wave + i is 1 KiB of [K tile | V^T tile]
+    auto dma_tile = [&](int t) {
+        if constexpr (KVG) return;
+        unsigned char* slot = kv_ring + (size_t)(t % 3) * 2 * TILEB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = 2 * wave + i;
+            const unsigned char* src = (p < NPIECE / 2 ? Kg + (size_t)t * TILEB + p * 1024 : Vg + (size_t)t * TILEB + (p - NPIECE / 2) * 1024) + lane * 16;
+            glds16(src, slot + p * 1024);
+        }
+    };
+
+    frag_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag_t*>(Qg + s * UNITB);
+    dma_tile(0);
+    if (nkt > 1) dma_tile(1);
+    frag_t kf[4];                           // KVG: always holds K(kt) at the top of tile kt (re-loaded in place after its last MFMA)
+    if constexpr (KVG) k_tile(0, kf);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    const int rr_base = c - 8 * h + 31;
+
+    // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V with V^T from the ring.
+    auto softmax_pv = [&](float (&sv)[16], int kt) {
+        const int k0 = kt * 32;
+        const unsigned char* vtile = (KVG ? Vg + (size_t)kt * TILEB : kv_ring + (size_t)(kt % 3) * 2 * TILEB + TILEB) + lane * (UNITB / 64);
+        frag_t vt[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            vt[0][t] = *reinterpret_cast<const frag_t*>(vtile + t * UNITB);
+            vt[1][t] = *reinterpret_cast<const frag_t*>(vtile + (2 + t) * UNITB);
+        }
+        if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sv[i] += b0[i]; sv[4 + i] += b1[i]; sv[8 + i] += b2[i]; sv[12 + i] += b3[i]; }
+        }
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+        mx = fmaxf(mx, sv[15]);
+        if (__builtin_amdgcn_ballot_w64(mx - m > RESCALE_THR) != 0ull) {     // deferred rescale (attention.hip)
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
+        l += psum;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            frag_t pfr;
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f16_t ph = (f16_t)sv[8 * t + j];
+                    pfr.hi[j] = ph;
+                    pfr.lo[j] = (f16_t)(sv[8 * t + j] - (float)ph);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
+            }
+            mma32(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
+            mma32(vt[1][t], pfr, o1);     //                   dd + 32
+        }
+    };
+
+    // key-tile ranges, WORKGROUP-uniform: [0, kt_a) saturated high for every wave (wave 0 has the smallest q - k), [kt_a, kt_b)
+    // band path (correct for any tile), [kt_b, nkt) saturated low for every wave (the last wave has the largest q - k)
+    int kt_a = Q0 - 31 - a.rsat_pos >= 0 ? (Q0 - 31 - a.rsat_pos) / 32 + 1 : 0;
+    kt_a = kt_a > nkt ? nkt : kt_a;
+    int kt_b = (Q0 + 32 * (NW - 1) + 31 - a.rsat_neg + 31) / 32;
+    kt_b = kt_b < kt_a ? kt_a : (kt_b > nkt ? nkt : kt_b);
+
+    // Saturated key tiles: delta is ONE value d*: c2p = Q_q.PK[d*] is a per-query constant, p2c = K_k.PQ[d*] a second product on the
+    // same K fragments (8 + 4 MFMA, no band).  One workgroup barrier per tile (ring hand-over).
+    auto sat_tiles = [&](int kt_lo, int kt_hi, int dstar) {
+        if (kt_lo >= kt_hi) return;
+        frag_t pqb[4], pkb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // broadcast fragments: every row / column is table row d*
+            pqb[s] = *reinterpret_cast<const frag_t*>(PQg + ((size_t)(dstar >> 5) * 2048 + (dstar & 31) * 8) * sizeof(T) + s * UNITB);
+            pkb[s] = *reinterpret_cast<const frag_t*>(PKg + ((size_t)(dstar >> 5) * 2048 + glc_pi32(dstar & 31) * 8) * sizeof(T) + s * UNITB);
+        }
+        float cq;
+        {
+            f32x16 t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pkb[s], qf[s], t);            // every row = PK[d*] . Q_c
+            cq = t[0];
+        }
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            if (kt + 2 < nkt) dma_tile(kt + 2);          // slot (kt - 1) % 3: its last readers retired before the barrier that ended tile kt - 1
+            if constexpr (!KVG) k_tile(kt, kf);
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = cq;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(kf[s], pqb[s], sacc);        // + K_k . PQ[d*] (same for every query column)
+            if constexpr (KVG) k_tile(kt + 1 < nkt ? kt + 1 : kt, kf);
+            float sv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
+            softmax_pv(sv, kt);
+            if constexpr (!KVG) wg_barrier_all();        // tiles kt + 1 (and kt + 2) are in the ring for everyone
+        }
+    };
+
+    if constexpr (!KVG) wg_barrier_all();  // tile 0 is in the ring
+    sat_tiles(0, kt_a, a.P - 1);
+
+    if (kt_a < kt_b) {
+        // ---- band prologue: this wave's c2p blocks L(kt_a - 1) (high block of the first band tile) and L(kt_a) (its low block) ----
+        {
+            frag_t pk[4];
+            f32x16 bacc;
+            load_rows(PKg, block_delta(q0, kt_a - 1).y, pk);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+            band_store(c2p_l + c * LROW + 32, bacc);            // ring half 1
+            load_rows(PKg, block_delta(q0, kt_a).y, pk);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+            band_store(c2p_l + c * LROW, bacc);                 // ring half 0
+            wave_lds_sync();
+        }
+        // Gather addresses of the c2p band.  xr = 32 (step parity): the ring half that holds this tile's LOW block; the column of band
+        // row rr is rr ^ xr.  On even steps that is lane base + immediate; on odd steps the xor depends on the lane, so the 16
+        // addresses are computed once here instead of 3 VALU per element and tile.
+        const float* c2p_even = c2p_l + c * LROW + rr_base;
+        const float* c2p_odd[SPLIT ? 1 : 16];              // (split operands: no registers to spare, the xor is recomputed)
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c2p_odd[i] = c2p_l + c * LROW + ((rr_base - (16 * (i >> 3) + (i & 7))) ^ 32);
+        }
+        // One band tile.  xr is a literal at both call sites (the loop is unrolled by two).  `pq` holds the rows of this wave's LOW
+        // block for tile kt, requested one tile ago: it is re-loaded IN PLACE for tile kt + 1 as soon as its last MFMA has issued.
+        frag_t pq[4], pqx[4];
+        load_rows(PQg, block_delta(q0, kt_a).x, pq);
+        if ((kt_a % NW) == wave) load_rows(PQg, block_delta(Q0 + 32 * NW, kt_a).x, pqx);
+        auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
+            const bool extra = (kt % NW) == wave;               // wave-uniform: this wave also computes the block nobody owns
+            frag_t pk[4];
+            load_rows(PKg, block_delta(q0, kt + 1).y, pk);     // PK rows of L(kt + 1): consumed after the gather
+            if constexpr (!KVG) k_tile(kt, kf);
+            float* img = p2c_img + (KVG ? (size_t)(kt & 1) * 32 * LROWP : 0);      // KVG: two images, alternating
+            // the gathered c2p band is the initial accumulator of S^T; reg i <-> key k0 + 16 (i>>3) + 8h + (i&7)
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kc = 16 * (i >> 3) + (i & 7);
+                if constexpr (SPLIT) sacc[i] = xr ? c2p_l[c * LROW + ((rr_base - kc) ^ 32)] : c2p_even[-kc];
+                else sacc[i] = xr ? *c2p_odd[i] : c2p_even[-kc];
+            }
+            // ---- p2c (needs only K and PQ): low block of this wave, and, one wave per tile, the high block of the last wave ----
+            f32x16 bacc, bacc2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pq[s], kf[s], bacc);
+            if (extra) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bacc2[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) mma32(pqx[s], kf[s], bacc2);
+            }
+            // ---- S^T = K Q^T + c2p ----
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+            // requests for the next tile, into the registers whose last MFMA has just issued
+            load_rows(PQg, block_delta(q0, kt + 1).x, pq);
+            if (((kt + 1) % NW) == wave) load_rows(PQg, block_delta(Q0 + 32 * NW, kt + 1).x, pqx);
+            if constexpr (KVG) k_tile(kt + 1 < nkt ? kt + 1 : kt, kf);     // in place: K(kt + 1)
+            else wg_barrier_lds();                              // X: every wave has finished gathering the previous tile's image
+            band_store(img + c * LROWP + 32 * wave, bacc);      // row = key lane (conflict-free); the gather applies pi
+            if (extra) band_store(img + c * LROWP + 32 * NW, bacc2);
+            if constexpr (KVG) wg_barrier_lds();                // Y: image complete (the other image is still being gathered by slower waves)
+            else wg_barrier_all();                              // Y: image complete; tile kt + 1 is in the ring for everyone
+            if (kt + 2 < nkt) dma_tile(kt + 2);                 // slot (kt - 1) % 3: every wave is past tile kt - 1
+            float sv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kc = 16 * (i >> 3) + (i & 7);                         // key offset minus 8h
+                const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);  // pi(key offset) minus 4h: image rows are in lane order
+                sv[i] = sacc[i] + img[(prow + 4 * h) * LROWP + 32 * wave + rr_base - kc];
+            }
+            f32x16 cacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], cacc);             // c2p of L(kt + 1)  [rr][query c]
+            softmax_pv(sv, kt);
+            band_store(c2p_l + c * LROW + (xr ^ 32), cacc);     // over the old high block (its gather is long retired)
+        };
+        for (int kt = kt_a;;) {
+            band_tile(kt, 0);
+            if (++kt >= kt_b) break;
+            band_tile(kt, 32);
+            if (++kt >= kt_b) break;
+        }
+    }
+
+    sat_tiles(kt_b, nkt, 0);
+
+    if (!active) return;
+    if (a.tile_flag && !a.tile_flag[(size_t)b * (Sp >> 5) + (q0 >> 5)]) return;     // pruned last layer: this tile is not read
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if constexpr (sizeof(T) == 2) {
+        store_acc32_wide<T>(o0, inv, reinterpret_cast<T*>(outp), h);
+        store_acc32_wide<T>(o1, inv, reinterpret_cast<T*>(outp) + 32, h);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            store4<OutT>(outp + 8 * g + 4 * h, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            store4<OutT>(outp + 32 + 8 * g + 4 * h, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+template <typename T, bool SPLIT, int NW, bool KVG> constexpr size_t wg_lds_bytes() {
+    return KVG ? ((size_t)NW * 32 * LROW + 2 * 32 * (32 * (NW + 1) + 4)) * sizeof(float)
+               : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
+}
+
+template <typename T, bool SPLIT, int NW, bool KVG> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
+    static std::atomic<unsigned> raised{0};
+    constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
+    static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
+    if (dbg) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG>, 64 * NW, lds);
+        fprintf(stderr, "[attn_wg] NW=%d lds=%zu bytes, occupancy API: %d workgroup(s) per CU\n", NW, lds, nb);
+    }
+    const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
+    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    return nullptr;
+}
+
+}  // namespace
+
+// Same shape contract as glc_launch_attention (attention.hip): head_dim == 64, Sp % 64 == 0, P % 32 == 0, fragment-major operands, offset table.
+const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a) {
+    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(wg): null pointer";
+    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(wg): bad shape";
+    if (a.sel_b || a.stamps) return "attention(wg): no row selection / stamps in this kernel";
+    if (dtype == GLC_DT_F32) {
+        if (!a.split) return "attention(wg): the fp32 mode runs this kernel on split-f16 units only";
+        return (a.variant & 8) ? launch_wg<float, true, 8, true>(st, a) : launch_wg<float, true, 8, false>(st, a);
+    }
+    if (a.split) return "attention(wg): split operands belong to the fp32 mode";
+    if (a.variant & 8) return dtype == GLC_DT_BF16 ? launch_wg<bf16_t, false, 4, true>(st, a) : launch_wg<f16_t, false, 4, true>(st, a);
+    return dtype == GLC_DT_BF16 ? launch_wg<bf16_t, false, 4, false>(st, a) : launch_wg<f16_t, false, 4, false>(st, a);
+}

@@ -394,8 +394,19 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
       KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
 
-    const int impl = e->attn_impl ? e->attn_impl : 2;        // MFMA band kernel for every operand type (fp32: 32x32x2 MFMAs); 1 = straightforward kernel
-    const bool asplit = e->attn_split && impl == 2 && dt == GLC_F32;        // fp32 mode: split-f16 operand units for the band kernel
+    // attention kernel: 3 = workgroup-shared band kernel (attention_wg.hip), 2 = per-wave band kernel (every operand type; fp32 native:
+    // 32x32x2 MFMAs), 1 = straightforward kernel.  Default, measured same-box at c3 (scripts/attn_bench.py): split-f16 units of the
+    // fp32 mode -> 3 (1.45 vs 1.80 ms per launch: MFMA-heavy, the 3 shared p2c MFMA blocks and the shared K / V^T ring pay);
+    // 16-bit operands -> 2 (0.70 vs 0.76 ms: at one MFMA per product the kernel is bound by instruction issue and latency, and
+    // the workgroup barrier per tile costs more than the 3 MFMAs and 3 loads it saves).  GLC_ATTN_WG=1 / 0 forces one or the other.
+    static const int wg_env = getenv("GLC_ATTN_WG") ? atoi(getenv("GLC_ATTN_WG")) : -1;      // developer A/B switch
+    const bool wg_pick = wg_env >= 0 ? wg_env != 0 : dt == GLC_F32;
+    int impl = e->attn_impl ? e->attn_impl : ((wg_pick && (dt != GLC_F32 || e->attn_split)) ? 3 : 2);
+    if (impl == 3 && dt == GLC_F32 && !e->attn_split) impl = 2;
+    const bool asplit = e->attn_split && impl >= 2 && dt == GLC_F32;        // fp32 mode: split-f16 operand units for the band kernels
+    auto launch_band = [&](const AttnArgs& aa) -> const char* {
+        return impl == 3 ? glc_launch_attention_wg(st, dt, aa) : glc_launch_attention(st, dt, impl, aa);
+    };
     const bool prune = e->prune_last && !e->keep_hidden && c.pooling == GLC_POOL_FIRST;
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
@@ -410,7 +421,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
-        { Prof p(e, PC_ATTN); KCHK(glc_launch_attention(st, dt, impl, a), false); }
+        { Prof p(e, PC_ATTN); KCHK(launch_band(a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
         { Prof p(e, PC_ATTN_OUT); KCHK(launch_gemm_auto(e, dt, EPI_RESID, o), false); }
@@ -433,7 +444,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         Prof p(e, PC_LAST);
         const LayerW& w = e->layers[c.layers - 1];
         const int R = B * (1 + Cc), Rpad = round_up(R, 256);
-        const bool band_sel = impl == 2;     // 16-bit: band kernel on the query tiles that hold selected rows; f32: row-selection kernel
+        const bool band_sel = impl >= 2;     // band kernel on the query tiles that hold selected rows; impl 1: row-selection kernel
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = band_sel ? 0 : 1;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit && band_sel;
@@ -443,7 +454,9 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         if (band_sel) {
             AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
             a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;
-            KCHK(glc_launch_attention(st, dt, 2, a), false);
+            // selected query tiles only: the per-wave kernel skips every other tile; a workgroup of the shared kernel would run all
+            // its waves for the one tile that holds the [CLS] / class-token rows
+            KCHK(e->attn_impl == 3 ? launch_band(a) : glc_launch_attention(st, dt, 2, a), false);
             KCHK(glc_launch_gather_sel(st, dt, e->CTX, e->sel_b, e->sel_q, e->CTXs, R, Sp, H), false);
         } else {
             GemmArgs gq;     // Q rows of the selection: the first H rows of the fused [3H,H] weight are the (pre-scaled) query projection
@@ -973,7 +986,7 @@ int glc_profile_read(glc_engine* e, const char** names, float* total_ms, int* la
 int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hidden = on != 0; return 0; }
 int glc_engine_set_prune_last_layer(glc_engine* e, int on) { if (!e) return -1; e->prune_last = on != 0; return 0; }
 int glc_debug_set_attention_impl(glc_engine* e, int impl) {
-    if (!e || impl < 0 || impl > 2) { set_err("bad attention impl"); return -1; }
+    if (!e || impl < 0 || impl > 3) { set_err("bad attention impl"); return -1; }
     e->attn_impl = impl;
     return 0;
 }
@@ -1058,19 +1071,22 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
  * variant is passed through to the kernel; stamps != 0 adds one launch of the s_memtime-instrumented build and prints
  * the per-tile segment cycles.  Returns ms per launch or < 0. */
 float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum) {
-    if (!e || iters <= 0 || e->dtype == GLC_F32 || e->lastB <= 0 || e->cfg.backbone != GLC_BACKBONE_DEBERTA) {
-        set_err("attn_bench: needs a 16-bit DeBERTa engine and a previous forward"); return -1.f;
+    if (!e || iters <= 0 || (e->dtype == GLC_F32 && !e->attn_split) || e->lastB <= 0 || e->cfg.backbone != GLC_BACKBONE_DEBERTA) {
+        set_err("attn_bench: needs a DeBERTa engine (16-bit, or fp32 with split-f16 attention) and a previous forward"); return -1.f;
     }
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHK(hipSetDevice(e->device), -1.f);
     const int B = e->lastB, Sp = e->lastSp, H = e->cfg.hidden, nh = e->cfg.heads;
     const LayerW& w = e->layers[0];
-    AttnArgs a{e->Qh, e->Kh, e->Vt, w.PK, w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant; a.otab = e->otabs[Sp];
+    const bool sp = e->dtype == GLC_F32;
+    AttnArgs a{e->Qh, e->Kh, e->Vt, sp ? w.PKs : w.PK, sp ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
+    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 11; a.otab = e->otabs[Sp]; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring
     hipStream_t st = e->stream;
-    for (int i = 0; i < 2; ++i) KCHK(glc_launch_attention(st, e->dtype, 2, a), -1.f);
+    const bool wg = (variant & 4) != 0;                       // bit 2: the workgroup-shared kernel (attention_wg.hip)
+    auto launch = [&]() -> const char* { return wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
+    for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);
-    for (int i = 0; i < iters; ++i) glc_launch_attention(st, e->dtype, 2, a);
+    for (int i = 0; i < iters; ++i) launch();
     HIPCHK(hipEventRecord(e->t1, st), -1.f);
     HIPCHK(hipEventSynchronize(e->t1), -1.f);
     float t = 0.f;
@@ -1089,7 +1105,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         for (size_t i = 0; i < n; ++i) { s1 += h[i]; s2 += (double)h[i] * h[i]; }
         checksum[0] = s1; checksum[1] = s2;
     }
-    if (stamps) {
+    if (stamps && !wg && !sp) {
         unsigned long long* dbuf = nullptr;
         const size_t ns = 64 * 4 * 8;
         if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {

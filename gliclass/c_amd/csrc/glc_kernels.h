@@ -84,8 +84,11 @@ struct AttnArgs {
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
     int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
 };
-// impl: 1 = simple (any T), 2 = MFMA band kernel (16-bit T only)
+// impl: 1 = simple (any T), 2 = MFMA band kernel, one independent wave per 32-query tile (attention.hip)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
+// impl 3: workgroup-shared band kernel (attention_wg.hip): K / V^T tiles through an LDS-DMA ring, p2c band shared by the waves of a
+// workgroup.  16-bit operands, or the fp32 mode's split-f16 units (a.split).
+const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a);
 
 #include <atomic>
 // CU count of the CURRENT device, cached per device ordinal (a session may span GPUs of different sizes)

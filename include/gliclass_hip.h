@@ -127,7 +127,7 @@ int glc_profile_read(glc_engine* e, const char** names, float* total_ms, int* la
  * glc_debug_keep_hidden(e,1) was set before the forward. */
 int glc_debug_keep_hidden(glc_engine* e, int on);
 int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems);
-/* Force the reference (non-MFMA) attention kernel: 0 auto, 1 simple, 2 mfma. */
+/* Attention kernel choice: 0 auto, 1 straightforward (non-MFMA), 2 per-wave MFMA band kernel, 3 workgroup-shared band kernel. */
 int glc_debug_set_attention_impl(glc_engine* e, int impl);
 
 /* clamp(bucket(q-k)+span, 0, 2span-1) for q-k in [-(S-1), S-1] at out[q-k+S-1] (float32 math as

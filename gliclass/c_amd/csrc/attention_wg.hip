@@ -369,6 +369,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     if constexpr (sizeof(T) == 2) {
         store_acc32_wide<T>(o0, inv, reinterpret_cast<T*>(outp), h);
         store_acc32_wide<T>(o1, inv, reinterpret_cast<T*>(outp) + 32, h);
+    } else if (a.ctx_gs) {
+        // group-split context rows (glc_kernels.h): the head's 64 columns are groups 2 hh (o0) and 2 hh + 1 (o1) of the row's
+        // [32 hi halves | 32 lo halves] groups; hi = f16(v), lo = f16(v - hi), 16-byte stores through the 16-bit store helper
+        f16_t* row = reinterpret_cast<f16_t*>(a.CTX) + ((size_t)b * Sp + q0 + c) * 2 * a.H + (size_t)(2 * hh) * 64;
+        f32x16 l0, l1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v0 = o0[i] * inv, v1 = o1[i] * inv;
+            l0[i] = v0 - (float)(f16_t)v0;
+            l1[i] = v1 - (float)(f16_t)v1;
+        }
+        store_acc32_wide<f16_t>(o0, inv, row, h);
+        store_acc32_wide<f16_t>(l0, 1.0f, row + 32, h);
+        store_acc32_wide<f16_t>(o1, inv, row + 64, h);
+        store_acc32_wide<f16_t>(l1, 1.0f, row + 96, h);
     } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

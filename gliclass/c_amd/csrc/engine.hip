@@ -67,6 +67,8 @@ struct glc_engine {
     bool w_presplit = false;        // weights of the split-f16 fp32 GEMMs are split once at load (encoder layers in fp32 mode; head projectors in every mode)
     bool dec_split = false;         // decoder backbone, fp32 mode: RoPE/layout pass writes split-f16 units, grouped-query attention on three-MFMA products
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
+    int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
+    bool last_gs = false;           // the last forward ran the group-split pipeline
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
@@ -390,10 +392,6 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     }
     { Prof p(e, PC_SCAN);
       KCHK(glc_launch_scan_rows(st, ids, mask, B, S, c.class_token_index, c.embed_class_token, e->klen, e->kfirst, e->cls_pos, e->cls_cnt, ccap), false); }
-    { Prof p(e, PC_EMBED);
-      KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
-    if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
-
     // attention kernel: 3 = workgroup-shared band kernel (attention_wg.hip), 2 = per-wave band kernel (every operand type; fp32 native:
     // 32x32x2 MFMAs), 1 = straightforward kernel.  Default, measured same-box at c3 (scripts/attn_bench.py): split-f16 units of the
     // fp32 mode -> 3 (1.45 vs 1.80 ms per launch: MFMA-heavy, the 3 shared p2c MFMA blocks and the shared K / V^T ring pay);
@@ -408,6 +406,21 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         return impl == 3 ? glc_launch_attention_wg(st, dt, aa) : glc_launch_attention(st, dt, impl, aa);
     };
     const bool prune = e->prune_last && !e->keep_hidden && c.pooling == GLC_POOL_FIRST;
+    // Group-split pipeline of the fp32 mode: the activations that feed GEMMs (X, H1, FF, CTX) are kept as [32 hi | 32 lo] f16 groups
+    // (same bytes as fp32), written by their producers, so that every projection runs on the 256-tile LDS-DMA kernel as a K' = 3K
+    // loop (gemm256s.hip, GS).  Needs the split-f16 weights and attention, the pruned last layer (its compact rows go back to plain
+    // fp32 and the small-M kernels) and shapes the 256-tile kernel takes; small forwards stay on the 128-tile split-K kernels.
+    bool gs = false;
+    if (dt == GLC_F32 && e->gs_mode > 0 && e->w_presplit && asplit && impl == 3 && prune && H % 256 == 0 && I % 256 == 0) {
+        GemmArgs t; t.Mpad = Mpad; t.N = H; t.K = H;
+        gs = e->gs_mode == 2 || !glc_gemm_small_m(t);
+    }
+    e->last_gs = gs;
+    { Prof p(e, PC_EMBED);
+      if (gs) KCHK(glc_launch_embed_gs(st, ids, mask, (const float*)e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false);
+      else KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
+    if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
         const bool last = prune && l == c.layers - 1;
@@ -415,24 +428,26 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit;
         if (last) break;
-        { Prof p(e, PC_QKV); KCHK(launch_gemm_auto(e, dt, EPI_QKV, g), false); }
+        { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-        a.split = asplit;
+        a.split = asplit; a.ctx_gs = gs;
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
         { Prof p(e, PC_ATTN); KCHK(launch_band(a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
-        { Prof p(e, PC_ATTN_OUT); KCHK(launch_gemm_auto(e, dt, EPI_RESID, o), false); }
-        { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
+        { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
+        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
+                                    : glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
-        { Prof p(e, PC_FFN1); KCHK(launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
+        { Prof p(e, PC_FFN1); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        { Prof p(e, PC_FFN2); KCHK(launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
-        { Prof p(e, PC_LN); KCHK(glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
+        { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
+        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H)
+                                    : glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
         if (e->keep_hidden)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     }
@@ -448,9 +463,11 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = band_sel ? 0 : 1;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit && band_sel;
-        KCHK(launch_gemm_auto(e, dt, EPI_QKV, g), false);
+        KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false);
         if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)B * (Sp >> 5), st), false);
-        KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
+        // (group-split pipeline: the compact rows leave it here — plain fp32, the rest of this layer runs on the small-M kernels)
+        if (gs) KCHK(glc_launch_gather_rows_gs(st, e->X, e->cls_pos, ccap, (float*)e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
+        else KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         if (band_sel) {
             AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
             a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;
@@ -639,6 +656,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
+    if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
         if (!create_decoder(e, tensors)) { glc_engine_destroy(e); return nullptr; }
@@ -983,6 +1001,12 @@ int glc_profile_read(glc_engine* e, const char** names, float* total_ms, int* la
     return n;
 }
 
+int glc_debug_set_group_split(glc_engine* e, int mode) {
+    if (!e || mode < 0 || mode > 2) { set_err("group_split: 0 off, 1 auto, 2 whenever the shapes allow"); return -1; }
+    e->gs_mode = mode;
+    return 0;
+}
+int glc_debug_last_forward_group_split(const glc_engine* e) { return e ? (e->last_gs ? 1 : 0) : -1; }
 int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hidden = on != 0; return 0; }
 int glc_engine_set_prune_last_layer(glc_engine* e, int on) { if (!e) return -1; e->prune_last = on != 0; return 0; }
 int glc_debug_set_attention_impl(glc_engine* e, int impl) {

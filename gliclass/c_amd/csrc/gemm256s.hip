@@ -41,8 +41,14 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
                                      (void __attribute__((address_space(3)))*)l, 16, 0, 0);
 }
 
-template <typename T, int EPI, bool VMODE>
+// GS (T = f16_t only): the operands of the fp32 mode.  A and W hold group-split rows (glc_kernels.h: every 32 fp32 values stored as
+// [32 hi halves | 32 lo halves], 128 bytes), and a product is the three f16 MFMAs a_lo*w_hi + a_hi*w_lo + a_hi*w_hi: the SAME
+// main loop over K' = 3K/32 steps, where step 3s + r fetches the (lo, hi) / (hi, lo) / (hi, hi) 64-byte parts of group s of the A
+// and W rows.  Epilogues: GELU (exact erf form) / BIAS write C in the GS format; RESID reads the residual in the GS format and
+// writes plain fp32 (the LayerNorm input); QKV writes split-f16 fragment units [8 hi | 8 lo] (glc_common.h f16x8s).
+template <typename T, int EPI, bool VMODE, bool GS = false>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile0, int ntn) {
+    static_assert(!GS || sizeof(T) == 2, "GS operands are f16 halves");
     typedef typename Frag<T>::type frag_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int wm = wave >> 2, wn = wave & 3;
@@ -68,16 +74,22 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     for (int i = 0; i < 2; ++i) {
         const int row = wave * 32 + i * 16 + lrow;
         const int ch = lch ^ swz4(row);
-        ga[i] = A + (size_t)(m0 + row) * K + ch * 8;
-        gw[i] = W + (size_t)(n0 + row) * K + ch * 8;
+        ga[i] = A + (size_t)(m0 + row) * (GS ? 2 * K : K) + ch * 8;
+        gw[i] = W + (size_t)(n0 + row) * (GS ? 2 * K : K) + ch * 8;
     }
     auto stage = [&](int st) {
         unsigned char* sa = smem256 + (st & (NSLOT - 1)) * STAGE + (wave * 32) * ROWB;
         unsigned char* sw = sa + TM * ROWB;
+        size_t oa, ow;                          // element offsets of this step's 32 k-values in the A / W rows
+        if constexpr (GS) {
+            const int s3 = st / 3, r3 = st - 3 * s3;
+            oa = (size_t)s3 * 64 + (r3 == 0 ? 32 : 0);
+            ow = (size_t)s3 * 64 + (r3 == 1 ? 32 : 0);
+        } else oa = ow = (size_t)st * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            glds16(ga[i] + (size_t)st * 32, sa + i * 16 * ROWB);
-            glds16(gw[i] + (size_t)st * 32, sw + i * 16 * ROWB);
+            glds16(ga[i] + oa, sa + i * 16 * ROWB);
+            glds16(gw[i] + ow, sw + i * 16 * ROWB);
         }
     };
 
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     // fragment read offsets: row r (+16 i keeps (r>>2)&3), logical chunk g -> physical g ^ swz4(r)
     const int aoff = (wm * 128 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
     const int boff = TM * ROWB + (wn * 64 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
-    const int nk = K / 32;
+    const int nk = GS ? 3 * (K / 32) : K / 32;
     const bool late = wm == 1;            // group 1 runs half a step behind group 0 (one extra barrier up front)
     frag_t af[8], bf[4];
 
@@ -203,23 +215,30 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         }
         // residual rows are fetched one 32-row chunk AHEAD of their use (16-byte coalesced loads): without this each
         // chunk exposed a full HBM round trip between its LDS read-back and its store (+4.7 us per tile measured)
-        vec8T rpre[4];
-        auto load_resid = [&](int c, vec8T (&r)[4]) {
+        vec8T rpre[4], rpre_lo[GS ? 4 : 1];
+        auto load_resid = [&](int c, vec8T (&r)[4], vec8T (&rl)[GS ? 4 : 1]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
-                r[k] = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) +
-                                                       (size_t)(m0 + wm * 128 + c * 32 + row) * N + n0 + wn * 64 + g8 * 8);
+                if constexpr (GS) {
+                    const int n = n0 + wn * 64 + g8 * 8;
+                    const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
+                    r[k] = *reinterpret_cast<const vec8T*>(rp);
+                    rl[k] = *reinterpret_cast<const vec8T*>(rp + 32);
+                } else {
+                    r[k] = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) +
+                                                           (size_t)(m0 + wm * 128 + c * 32 + row) * N + n0 + wn * 64 + g8 * 8);
+                }
             }
         };
-        if (EPI == EPI_RESID) load_resid(0, rpre);
+        if (EPI == EPI_RESID) load_resid(0, rpre, rpre_lo);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            vec8T rcur[4];
+            vec8T rcur[4], rcur_lo[GS ? 4 : 1];
             if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rcur[k] = rpre[k];
-                if (c + 1 < 4) load_resid(c + 1, rpre);
+                for (int k = 0; k < 4; ++k) { rcur[k] = rpre[k]; if constexpr (GS) rcur_lo[k] = rpre_lo[k]; }
+                if (c + 1 < 4) load_resid(c + 1, rpre, rpre_lo);
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
@@ -228,8 +247,12 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                     f32x4 v = acc[2 * c + ii][j];
                     v[0] += bj[j][0]; v[1] += bj[j][1]; v[2] += bj[j][2]; v[3] += bj[j][3];
                     if (EPI == EPI_GELU) {
-                        const f32x2 g0 = glc_gelu2((f32x2){v[0], v[1]}), g1 = glc_gelu2((f32x2){v[2], v[3]});
-                        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                        if constexpr (GS) {     // fp32 mode: the erf form at fp32 resolution (the 16-bit epilogue's logistic fit is only f16-exact)
+                            v[0] = glc_gelu(v[0]); v[1] = glc_gelu(v[1]); v[2] = glc_gelu(v[2]); v[3] = glc_gelu(v[3]);
+                        } else {
+                            const f32x2 g0 = glc_gelu2((f32x2){v[0], v[1]}), g1 = glc_gelu2((f32x2){v[2], v[3]});
+                            v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                        }
                     }
                     *reinterpret_cast<f32x4*>(stg + (ii * 16 + r16) * 68 + j * 16 + 4 * g) = v;
                 }
@@ -245,20 +268,33 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 const int n = n0 + wn * 64 + g8 * 8;
                 if (EPI == EPI_RESID) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rcur[k][e];
+                    for (int e = 0; e < 8; ++e) v[e] += GS ? (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e] : (float)rcur[k][e];
                 }
-                vec8T o;
+                vec8T o, ol;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
+                for (int e = 0; e < 8; ++e) { o[e] = (T)v[e]; if constexpr (GS) ol[e] = (T)(v[e] - (float)o[e]); }
                 if (EPI == EPI_QKV) {
                     if (m < p.Mvalid) {
                         int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
                         while (sq >= p.Sp) { sq -= p.Sp; ++b; }          // a 256-row tile spans <= 5 sequences (Sp >= 64)
                         const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;     // dd is a multiple of 8: one 16-B unit
                         const int bh = b * p.nh + hh;
-                        T* dst = which == 0 ? reinterpret_cast<T*>(p.Qh) + glc_qoff(p.Sp, bh, sq, dd)
-                                            : reinterpret_cast<T*>(p.Kh) + glc_koff(p.Sp, bh, sq, dd);
-                        *reinterpret_cast<vec8T*>(dst) = o;
+                        const size_t off = which == 0 ? glc_qoff(p.Sp, bh, sq, dd) : glc_koff(p.Sp, bh, sq, dd);
+                        T* base = reinterpret_cast<T*>(which == 0 ? p.Qh : p.Kh);
+                        if constexpr (GS) {         // split-f16 unit: the 8 elements' 32 bytes are [8 hi | 8 lo]
+                            *reinterpret_cast<vec8T*>(base + 2 * off) = o;
+                            *reinterpret_cast<vec8T*>(base + 2 * off + 8) = ol;
+                        } else *reinterpret_cast<vec8T*>(base + off) = o;
+                    }
+                } else if constexpr (GS) {
+                    if (EPI == EPI_RESID) {         // plain fp32 row (LayerNorm input)
+                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
+                        *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else {                        // GS row
+                        T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * N + (n >> 5) * 64 + (n & 31);
+                        *reinterpret_cast<vec8T*>(cp) = o;
+                        *reinterpret_cast<vec8T*>(cp + 32) = ol;
                     }
                 } else {
                     *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n) = o;
@@ -290,14 +326,21 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 const int idx = lane + 64 * k, dd = idx >> 2, kg = idx & 3;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8 + 4);
-                vec8T o;
+                vec8T o, ol;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = (T)lo[e]; o[4 + e] = (T)hi[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (T)lo[e]; o[4 + e] = (T)hi[e];
+                    if constexpr (GS) { ol[e] = (T)(lo[e] - (float)o[e]); ol[4 + e] = (T)(hi[e] - (float)o[4 + e]); }
+                }
                 const int m = m0 + wm * 128 + c * 32 + kg * 8;           // first of 8 consecutive keys
                 if (m < p.Mvalid) {
                     int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
                     while (sq >= p.Sp) { sq -= p.Sp; ++b; }
-                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + glc_voff(p.Sp, b * p.nh + hh, dd, sq)) = o;
+                    const size_t off = glc_voff(p.Sp, b * p.nh + hh, dd, sq);
+                    if constexpr (GS) {
+                        *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + 2 * off) = o;
+                        *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + 2 * off + 8) = ol;
+                    } else *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + off) = o;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -306,11 +349,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     }
 }
 
-template <typename T, int EPI, bool VMODE> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+template <typename T, int EPI, bool VMODE, bool GS = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
     static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
-    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
-    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
     return nullptr;
 }
 template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmArgs& a) {
@@ -334,6 +377,33 @@ template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmAr
 static bool gemm256s_supported(int dtype, const GemmArgs& a) {
     return (dtype == GLC_DT_BF16 || dtype == GLC_DT_F16) && a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 &&
            a.K > 0 && a.K % 32 == 0;
+}
+
+bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi) {
+    if (!(a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 32 == 0)) return false;
+    if (epi == EPI_QKV) return a.H % 256 == 0 && a.N == 3 * a.H && a.Sp % 64 == 0 && a.Sp >= 64 && a.nh * 64 == a.H;
+    return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID;
+}
+
+// fp32 mode on group-split operands (see the kernel header): T = f16 halves, K' = 3K/32 steps.
+const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a) {
+    if (!glc_gemm256s_gs_supported(a, epi)) return "gemm256s(gs): unsupported shape";
+    if (!a.A || !a.W) return "gemm256s(gs): null operand";
+    if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256s(gs): null QKV output"; }
+    else if (!a.C) return "gemm256s(gs): null output";
+    if (epi == EPI_RESID && !a.resid) return "gemm256s(gs): null residual";
+    const int ntn = a.N / TN;
+    switch (epi) {
+        case EPI_BIAS: return launch_e<f16_t, EPI_BIAS, false, true>(st, a, 0, ntn);
+        case EPI_GELU: return launch_e<f16_t, EPI_GELU, false, true>(st, a, 0, ntn);
+        case EPI_RESID: return launch_e<f16_t, EPI_RESID, false, true>(st, a, 0, ntn);
+        case EPI_QKV: {
+            const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
+            const char* m = launch_e<f16_t, EPI_QKV, false, true>(st, a, nq, nqk - nq);
+            return m ? m : launch_e<f16_t, EPI_QKV, true, true>(st, a, nqk, ntn - nqk);
+        }
+    }
+    return "gemm256s(gs): bad epilogue";
 }
 
 // Host-side shape contract: 16-bit T; Mpad % 256 == 0 (buffers allocated with Mpad rows), N % 256 == 0,

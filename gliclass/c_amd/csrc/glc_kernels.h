@@ -50,6 +50,19 @@ inline const char* glc_launch_gemm_auto(hipStream_t st, int dtype, int epi, cons
 const char* glc_launch_layernorm(hipStream_t st, int dtype, const void* X, void* Y, const float* gamma,
                                  const float* beta, float eps, int M, int H);
 
+// ---- group-split ("GS") activations of the fp32 mode (rows.hip): a row of K fp32 values kept in the same 4 K bytes as K / 32 groups
+// of [32 hi halves | 32 lo halves] (x = hi + lo), the operand image of the split-f16 GEMMs ----
+const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H);
+const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_t* mask, const float* table, const float* gamma,
+                                const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id);
+const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* cls_pos, int c_cap, float* Xs, int* sel_b, int* sel_q,
+                                      unsigned char* tile_flag, int B, int Sp, int H, int C);
+// 256x256 LDS-DMA GEMM on GS operands (gemm256s.hip): A [Mpad, K] and W [N, K] in the GS format; three f16 MFMAs per product
+// (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi), i.e. a K' = 3K loop of the 16-bit kernel.  EPI_GELU / EPI_BIAS: C in the GS format;
+// EPI_RESID: resid in the GS format, C plain fp32 (the LayerNorm input); EPI_QKV: Q / K / V^T as split-f16 units (qkv_split).
+bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi);
+const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a);
+
 // Embedding gather + LayerNorm + mask (modeling_deberta_v2.py:533,550,552-559) on the padded
 // [B, Sp] grid (positions s >= S behave as padding); also writes the additive key bias
 // kbias[b*Sp+s] = mask ? 0 : -1e30.
@@ -83,6 +96,7 @@ struct AttnArgs {
     unsigned long long* stamps = nullptr;
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
     int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
+    int ctx_gs = 0;                                   // workgroup-shared kernel, split operands: write CTX rows in the GS format (see below)
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel, one independent wave per 32-query tile (attention.hip)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);

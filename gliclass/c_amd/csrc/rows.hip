@@ -54,6 +54,115 @@ __device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restri
     }
 }
 
+// ---- group-split ("GS") activations of the fp32 mode ----
+// A row of K fp32 values is stored in the same 4 K bytes as K/32 groups of [32 hi halves | 32 lo halves], x = hi + lo with
+// hi = f16(x), lo = f16(x - hi) — the row image the split-f16 GEMMs consume (gemm.hip presplit weights use the same format), so the
+// 256-tile LDS-DMA GEMM can fetch hi and lo parts of a 32-deep K step as plain 64-byte row pieces.  Element e of a row lives at
+// halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
+typedef __attribute__((ext_vector_type(8))) _Float16 gs_h8;
+__device__ __forceinline__ void gs_store8(f16_t* row, int e0, const float (&v)[8]) {      // e0 % 8 == 0
+    gs_h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; lo[e] = (f16_t)(v[e] - (float)h); }
+    f16_t* p = row + (e0 >> 5) * 64 + (e0 & 31);
+    *reinterpret_cast<gs_h8*>(p) = hi;
+    *reinterpret_cast<gs_h8*>(p + 32) = lo;
+}
+__device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]) {
+    const f16_t* p = row + (e0 >> 5) * 64 + (e0 & 31);
+    const gs_h8 hi = *reinterpret_cast<const gs_h8*>(p), lo = *reinterpret_cast<const gs_h8*>(p + 32);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)hi[e] + (float)lo[e];
+}
+// LayerNorm of one fp32 row by one wave, output in the GS format (8 elements per lane and chunk)
+template <bool MASKED>
+__device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_t* __restrict__ y, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps, int H, float mk, int lane) {
+    const int nch = H / 8;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8), b = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[c][e] = a[e]; v[c][4 + e] = b[e]; s += a[e] + b[e]; }
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (lane + 64 * c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r = (v[c][e] - mean) * rstd * gamma[ch * 8 + e] + beta[ch * 8 + e];
+                if (MASKED) r *= mk;
+                o[e] = r;
+            }
+            gs_store8(y, ch * 8, o);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int M, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
+}
+__global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+                                                       const float* __restrict__ table, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, f16_t* __restrict__ X,
+                                                       float* __restrict__ kbias, int B, int S, int Sp, int H, int vocab, int pad_id) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row in the padded [B, Sp] grid
+    if (row >= B * Sp) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / Sp, s = row - b * Sp;
+    long long id = pad_id;
+    float mk = 0.f;
+    if (s < S) {
+        id = ids[(size_t)b * S + s];
+        mk = mask[(size_t)b * S + s] != 0 ? 1.f : 0.f;
+        if (id < 0 || id >= vocab) id = pad_id;
+    }
+    if (lane == 0) kbias[row] = mk != 0.f ? 0.f : GLC_NEG_BIG;
+    ln_row_wave_gs<true>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane);
+}
+// pruned last layer: rows the head reads, GS hidden states -> plain fp32 compact rows (that layer runs on the fp32-format kernels)
+__global__ __launch_bounds__(256) void gather_rows_gs_kernel(const f16_t* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
+                                                             float* __restrict__ Xs, int* __restrict__ sel_b, int* __restrict__ sel_q,
+                                                             unsigned char* __restrict__ tile_flag, int B, int Sp, int H, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * (1 + C)) return;
+    const int lane = threadIdx.x & 63;
+    int b = r, pos = 0;
+    if (r >= B) {
+        const int rr = r - B, j = rr % C;
+        b = rr / C;
+        pos = j < c_cap ? cls_pos[(size_t)b * c_cap + j] : -1;
+        if (pos < 0) pos = 0;
+    }
+    if (lane == 0) { sel_b[r] = b; sel_q[r] = pos; if (tile_flag) tile_flag[(size_t)b * (Sp >> 5) + (pos >> 5)] = 1; }
+    const f16_t* src = X + ((size_t)b * Sp + pos) * 2 * H;
+    for (int i = lane; i < H / 8; i += 64) {
+        float v[8];
+        gs_load8(src, i * 8, v);
+        *reinterpret_cast<f32x4*>(Xs + (size_t)r * H + i * 8) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(Xs + (size_t)r * H + i * 8 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M, int H) {
@@ -277,6 +386,30 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
         hipLaunchKernelGGL(embed_kernel<T>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, (const T*)table, gamma, beta, eps,
                            (T*)X, kbias, B, S, Sp, H, vocab, pad_id);
     });
+    return nullptr;
+}
+
+const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H) {
+    if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm_gs: bad args";
+    if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "layernorm_gs: unsupported hidden size";
+    hipLaunchKernelGGL(layernorm_gs_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
+    return nullptr;
+}
+
+const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_t* mask, const float* table, const float* gamma,
+                                const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id) {
+    if (B <= 0 || S <= 0 || Sp < S || !ids || !mask || !table || !X || !kbias) return "embed_gs: bad args";
+    if (pad_id < 0 || pad_id >= vocab) return "embed_gs: pad id outside vocab";
+    if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "embed_gs: unsupported hidden size";
+    hipLaunchKernelGGL(embed_gs_kernel, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id);
+    return nullptr;
+}
+
+const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* cls_pos, int c_cap, float* Xs, int* sel_b, int* sel_q,
+                                      unsigned char* tile_flag, int B, int Sp, int H, int C) {
+    if (B <= 0 || C < 0 || !X || !cls_pos || !Xs || !sel_b || !sel_q || H % 32) return "gather_rows_gs: bad args";
+    const int rows = B * (1 + C);
+    hipLaunchKernelGGL(gather_rows_gs_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
     return nullptr;
 }
 

@@ -95,6 +95,14 @@ class Engine:
         if self.L.glc_engine_set_length_buckets(self.h, int(max_groups)) != 0:
             raise self._err("glc_engine_set_length_buckets")
 
+    def set_group_split(self, mode):
+        """fp32 mode: 0 = plain fp32 activations + 128-tile split GEMMs, 1 = auto, 2 = group-split pipeline whenever the shapes allow"""
+        if self.L.glc_debug_set_group_split(self.h, int(mode)) != 0:
+            raise self._err("glc_debug_set_group_split")
+
+    def last_group_split(self):
+        return bool(self.L.glc_debug_last_forward_group_split(self.h))
+
     def keep_hidden(self, on=True):
         self.L.glc_debug_keep_hidden(self.h, int(on))
 

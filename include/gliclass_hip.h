@@ -130,6 +130,11 @@ int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems)
 /* Attention kernel choice: 0 auto, 1 straightforward (non-MFMA), 2 per-wave MFMA band kernel, 3 workgroup-shared band kernel. */
 int glc_debug_set_attention_impl(glc_engine* e, int impl);
 
+/* fp32 mode: the group-split pipeline (activations kept as [32 hi | 32 lo] f16 groups, every projection on the 256-tile LDS-DMA
+ * kernel).  mode 0 off, 1 auto (default: forwards large enough to fill the chip), 2 whenever the shapes allow (tests). */
+int glc_debug_set_group_split(glc_engine* e, int mode);
+int glc_debug_last_forward_group_split(const glc_engine* e);
+
 /* clamp(bucket(q-k)+span, 0, 2span-1) for q-k in [-(S-1), S-1] at out[q-k+S-1] (float32 math as
  * torch).  Pure host function (no GPU needed). */
 void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out);

@@ -534,3 +534,31 @@ def test_second_device_gives_identical_results(weights_for):
             assert np.array_equal(a, b), dtype
         finally:
             e0.close(); e1.close()
+
+
+@pytest.mark.parametrize("cname", ["mini", "small"])
+def test_group_split_pipeline_vs_oracle_and_plain_fp32(cname, engines, weights_for):
+    """fp32 mode, the two activation formats: plain fp32 rows + 128-tile split-f16 GEMMs (small forwards) and group-split rows
+    ([32 hi | 32 lo] f16 groups) + the 256-tile LDS-DMA GEMM as a K' = 3K loop (large forwards; forced here).  Same arithmetic
+    (three f16 MFMAs per product, fp32 accumulation), different tiling and summation order: both against the oracle, and against
+    each other far inside the f32 bound.  Ragged rows, S that is no multiple of 64, rows without labels."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for(cname)
+    eng = engines(cname, "f32")
+    shapes = ((3, 200, 3, [3, 0, 2], 61), (2, 700, 4, None, 62), (9, 64, 2, None, 63), (1, 1100, 5, None, 64)) if cname == "mini" else ((4, 300, 4, [4, 1, 0, 3], 65),)
+    try:
+        for (B, S, Cn, lpr, seed) in shapes:
+            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=seed, ragged=True, labels_per_row=lpr)
+            ref = oracle_c.forward(cfg, w, ids, mask)
+            eng.set_group_split(0)
+            plain = eng.forward(ids, mask)
+            assert not eng.last_group_split()
+            eng.set_group_split(2)
+            gs = eng.forward(ids, mask)
+            assert eng.last_group_split()
+            assert np.isfinite(gs).all()
+            assert np.abs(sig(gs) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
+            assert np.abs(sig(gs) - sig(plain)).max() <= 1e-4, (B, S)     # each sits ~1e-5 from the oracle; GS rows also carry 22 instead of 24 bits
+    finally:
+        eng.set_group_split(1)

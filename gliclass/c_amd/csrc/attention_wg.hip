@@ -127,10 +127,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + off + s * UNITB);
     };
+    // One fragment unit out of the ring.  16-bit operands: the unit is the linear copy of its 1 KiB in HBM (16 B per lane).  Split units
+    // (32 B per lane in HBM: [8 hi | 8 lo]) are re-arranged by the DMA into [64 lanes x hi | 64 lanes x lo]: read lane-strided at 32 B
+    // the two ds_read_b128 of a fragment were 2-way bank conflicts (SQ_LDS_BANK_CONFLICT = 26 % of the kernel's LDS cycles).
+    auto ring_unit = [&](const unsigned char* unit) -> frag_t {
+        if constexpr (SPLIT) {
+            frag_t f;
+            f.hi = *reinterpret_cast<const f16x8*>(unit + lane * 16);
+            f.lo = *reinterpret_cast<const f16x8*>(unit + 1024 + lane * 16);
+            return f;
+        } else return *reinterpret_cast<const frag_t*>(unit + lane * 16);
+    };
     auto k_tile = [&](int t, frag_t (&f)[4]) {                  // the 4 fragment units of key tile t: from the ring, or (KVG) from global
-        const unsigned char* tile = KVG ? Kg + (size_t)t * TILEB : kv_ring + (size_t)(t % 3) * 2 * TILEB;
+        if constexpr (KVG) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(tile + s * UNITB + lane * (UNITB / 64));
+            for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(Kg + (size_t)t * TILEB + s * UNITB + lane * (UNITB / 64));
+        } else {
+            const unsigned char* tile = kv_ring + (size_t)(t % 3) * 2 * TILEB;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f[s] = ring_unit(tile + s * UNITB);
+        }
     };
     auto band_store = [&](float* dst, const f32x16& v) {           // 4 consecutive rr per register group
 #pragma unroll
@@ -144,8 +160,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = 2 * wave + i;
-            const unsigned char* src = (p < NPIECE / 2 ? Kg + (size_t)t * TILEB + p * 1024 : Vg + (size_t)t * TILEB + (p - NPIECE / 2) * 1024) + lane * 16;
-            glds16(src, slot + p * 1024);
+            if constexpr (SPLIT) {
+                // piece p = (unit `wave` of [K | V^T], part i): every lane fetches the hi (i = 0) or lo (i = 1) 16 bytes of ITS 32-byte
+                // entry, so the unit lands as [64 x hi | 64 x lo] (the per-lane source address makes the DMA a gather)
+                const unsigned char* ubase = wave < 4 ? Kg + (size_t)t * TILEB + wave * UNITB : Vg + (size_t)t * TILEB + (wave - 4) * UNITB;
+                glds16(ubase + lane * 32 + i * 16, slot + p * 1024);
+            } else {
+                const unsigned char* src = (p < NPIECE / 2 ? Kg + (size_t)t * TILEB + p * 1024 : Vg + (size_t)t * TILEB + (p - NPIECE / 2) * 1024) + lane * 16;
+                glds16(src, slot + p * 1024);
+            }
         }
     };
 
@@ -166,12 +189,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V with V^T from the ring.
     auto softmax_pv = [&](float (&sv)[16], int kt) {
         const int k0 = kt * 32;
-        const unsigned char* vtile = (KVG ? Vg + (size_t)kt * TILEB : kv_ring + (size_t)(kt % 3) * 2 * TILEB + TILEB) + lane * (UNITB / 64);
         frag_t vt[2][2];
+        if constexpr (KVG) {
+            const unsigned char* vtile = Vg + (size_t)kt * TILEB + lane * (UNITB / 64);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            vt[0][t] = *reinterpret_cast<const frag_t*>(vtile + t * UNITB);
-            vt[1][t] = *reinterpret_cast<const frag_t*>(vtile + (2 + t) * UNITB);
+            for (int t = 0; t < 2; ++t) {
+                vt[0][t] = *reinterpret_cast<const frag_t*>(vtile + t * UNITB);
+                vt[1][t] = *reinterpret_cast<const frag_t*>(vtile + (2 + t) * UNITB);
+            }
+        } else {
+            const unsigned char* vtile = kv_ring + (size_t)(kt % 3) * 2 * TILEB + TILEB;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                vt[0][t] = ring_unit(vtile + t * UNITB);
+                vt[1][t] = ring_unit(vtile + (2 + t) * UNITB);
+            }
         }
         if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);

@@ -15,7 +15,7 @@ out = sys.argv[1]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"void ", "", n)
-    return n[:90]
+    return n[:110]
 
 
 def find(pattern):
@@ -54,14 +54,21 @@ for tag, corr in (("fetch", 2.0), ("write", 1.0)):
     for name, (tot, n) in acc.items():
         traffic.setdefault(name, {})[tag + "_bytes_per_launch"] = tot / n * 1024 * corr
 
-# bench.py reads this (committed as profiles/traffic.json) for roofline.traffic of its dominant kernel class
+# bench.py reads this (committed, merged per dtype, as profiles/traffic.json) for roofline.traffic of its dominant kernel class
 import json
-cls = {"attention": r"attn_band_kernel", "gemm_ffn1_gelu": r"gemm256s?_kernelIDF16_Li1ELb0", "gemm_qkv": r"gemm256s?_kernelIDF16_Li3ELb0",
-       "gemm_ffn2": r"gemm256s?_kernelIDF16_Li2ELb0"}
+dtype = sys.argv[2] if len(sys.argv) > 2 else "f16"
+config = sys.argv[3] if len(sys.argv) > 3 else "base:64:1024"
+if dtype == "f32":      # default mode: split-f16 attention (workgroup-shared kernel) and group-split GEMMs (gemm256s GS = last template flag 1)
+    cls = {"attention": r"attn_wg_kernelIfLb1", "gemm_ffn1_gelu": r"gemm256s_kernelIDF16_Li1ELb0ELb1", "gemm_qkv": r"gemm256s_kernelIDF16_Li3ELb0ELb1",
+           "gemm_ffn2": r"gemm256s_kernelIDF16_Li2ELb0ELb1"}
+else:
+    cls = {"attention": r"attn_band_kernel", "gemm_ffn1_gelu": r"gemm256s?_kernelIDF16b?_Li1ELb0ELb0", "gemm_qkv": r"gemm256s?_kernelIDF16b?_Li3ELb0ELb0",
+           "gemm_ffn2": r"gemm256s?_kernelIDF16b?_Li2ELb0ELb0"}
 outj = {}
 for c, pat in cls.items():
     for name, v in traffic.items():
         if re.search(pat, name) and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
             outj[c] = dict(kernel=name, hbm_bytes_per_launch=v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], **v)
-json.dump(dict(source=os.path.basename(out.rstrip("/")), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH x2 (gfx950)", kernels=outj),
+json.dump({dtype: dict(config=config, source=os.path.basename(out.rstrip("/")),
+                       note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH x2 (gfx950)", kernels=outj)},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)

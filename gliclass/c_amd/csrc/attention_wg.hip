@@ -57,8 +57,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
 
 // KVG = K / V^T fragments straight from global memory, per wave (no ring); the LDS it frees double-buffers the p2c image, which
 // removes barrier X: ONE workgroup barrier per band tile, none in saturated tiles.
-template <typename T, bool SPLIT, int NW, bool KVG>
+// STAG (NW = 8): the two halves of the workgroup (waves 0-3 / 4-7, SIMD partners pairwise) each share their OWN p2c image (5 blocks per
+// 4 waves) and run the band loop HALF A TILE apart: the tile body is two phases, P1 = [S^T, p2c MFMAs, image stores] and P2 = [gathers,
+// softmax, P.V, next c2p block], with one workgroup barrier after each; the late half enters the loop one barrier later, so on every SIMD
+// one wave is in the matrix-heavy phase while its partner is in the VALU / LDS-heavy one (the staggered-wave-group idea of gemm256s.hip).
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
+    static_assert(!STAG || (NW == 8 && !KVG), "the stagger pairs the two 4-wave halves of an 8-wave workgroup");
     static_assert(!SPLIT || sizeof(T) == 4, "split operands live in the fp32 layouts");
     static_assert(SPLIT || sizeof(T) == 2, "16-bit operands or split-f16 units");
     typedef typename WgFrag<SPLIT, T>::type frag_t;
@@ -66,20 +71,24 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     constexpr int TILEB = 4 * UNITB;                 // one K tile, or one V^T tile
     constexpr int NPIECE = 2 * TILEB / 1024;         // 1-KiB DMA pieces per key tile (K then V^T): 8 or 16 = 2 per wave
     static_assert(KVG || NPIECE == 2 * NW, "two DMA pieces per wave and tile");
-    constexpr int LROWP = 32 * (NW + 1) + 4;         // floats per p2c image row
+    constexpr int NSH = STAG ? 4 : NW;               // waves that share one p2c image
+    constexpr int NIMG = (KVG || STAG) ? 2 : 1;      // images: KVG alternates two, STAG keeps one per half
+    constexpr int LROWP = 32 * (NSH + 1) + 4;        // floats per p2c image row
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int Sp = a.Sp;
 
     float* c2p_l = reinterpret_cast<float*>(smem_wg) + (size_t)wave * 32 * LROW;                     // this wave's ring [32 q][64 + 4]
     float* p2c_img = reinterpret_cast<float*>(smem_wg) + (size_t)NW * 32 * LROW;                     // shared [32 keys][LROWP]
-    unsigned char* kv_ring = smem_wg + ((size_t)NW * 32 * LROW + 32 * LROWP) * sizeof(float);        // 3 x (K tile | V^T tile)
+    unsigned char* kv_ring = smem_wg + ((size_t)NW * 32 * LROW + NIMG * 32 * LROWP) * sizeof(float);  // 3 x (K tile | V^T tile)
+    const int grp = STAG ? wave >> 2 : 0, wl = STAG ? wave & 3 : wave;      // image-sharing group and this wave's slot in it
 
     // XCD-aware decode of the 1-D grid: every query block of one (batch, head) gets the same id % 8 (shared L2 for its K / V^T)
     const int nqb = (Sp + 32 * NW - 1) / (32 * NW);
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int bh = xcd + 8 * (jj / nqb);
     const int Q0 = (jj % nqb) * 32 * NW;
+    const int QX = Q0 + 32 * (NSH * grp + NSH);           // the query tile whose LOW block is the group's unowned (last high) block
     if (bh >= a.B * a.nh) return;                       // workgroup-uniform
     const int b = bh / a.nh, hh = bh - b * a.nh;
     const int q0 = Q0 + 32 * wave;                      // this wave's query tile (may lie past Sp in the last block: computes, never stores)
@@ -329,13 +338,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
         // block for tile kt, requested one tile ago: it is re-loaded IN PLACE for tile kt + 1 as soon as its last MFMA has issued.
         frag_t pq[4], pqx[4];
         load_rows(PQg, block_delta(q0, kt_a).x, pq);
-        if ((kt_a % NW) == wave) load_rows(PQg, block_delta(Q0 + 32 * NW, kt_a).x, pqx);
+        if ((kt_a % NSH) == wl) load_rows(PQg, block_delta(QX, kt_a).x, pqx);
         auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
-            const bool extra = (kt % NW) == wave;               // wave-uniform: this wave also computes the block nobody owns
+            const bool extra = (kt % NSH) == wl;                // wave-uniform: this wave also computes the block nobody owns
             frag_t pk[4];
             load_rows(PKg, block_delta(q0, kt + 1).y, pk);     // PK rows of L(kt + 1): consumed after the gather
             if constexpr (!KVG) k_tile(kt, kf);
-            float* img = p2c_img + (KVG ? (size_t)(kt & 1) * 32 * LROWP : 0);      // KVG: two images, alternating
+            float* img = p2c_img + (KVG ? (size_t)(kt & 1) * 32 * LROWP : (size_t)grp * 32 * LROWP);      // KVG: two images, alternating; STAG: one per half
             // the gathered c2p band is the initial accumulator of S^T; reg i <-> key k0 + 16 (i>>3) + 8h + (i&7)
             f32x16 sacc;
 #pragma unroll
@@ -361,11 +370,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
             // requests for the next tile, into the registers whose last MFMA has just issued
             load_rows(PQg, block_delta(q0, kt + 1).x, pq);
-            if (((kt + 1) % NW) == wave) load_rows(PQg, block_delta(Q0 + 32 * NW, kt + 1).x, pqx);
+            if (((kt + 1) % NSH) == wl) load_rows(PQg, block_delta(QX, kt + 1).x, pqx);
             if constexpr (KVG) k_tile(kt + 1 < nkt ? kt + 1 : kt, kf);     // in place: K(kt + 1)
-            else wg_barrier_lds();                              // X: every wave has finished gathering the previous tile's image
-            band_store(img + c * LROWP + 32 * wave, bacc);      // row = key lane (conflict-free); the gather applies pi
-            if (extra) band_store(img + c * LROWP + 32 * NW, bacc2);
+            else if constexpr (!STAG) wg_barrier_lds();         // X: every wave has finished gathering the previous tile's image
+            // (STAG: the barrier that ended this half's previous P2 already separates those gathers from these stores)
+            band_store(img + c * LROWP + 32 * wl, bacc);        // row = key lane (conflict-free); the gather applies pi
+            if (extra) band_store(img + c * LROWP + 32 * NSH, bacc2);
             if constexpr (KVG) wg_barrier_lds();                // Y: image complete (the other image is still being gathered by slower waves)
             else wg_barrier_all();                              // Y: image complete; tile kt + 1 is in the ring for everyone
             if (kt + 2 < nkt) dma_tile(kt + 2);                 // slot (kt - 1) % 3: every wave is past tile kt - 1
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             for (int i = 0; i < 16; ++i) {
                 const int kc = 16 * (i >> 3) + (i & 7);                         // key offset minus 8h
                 const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);  // pi(key offset) minus 4h: image rows are in lane order
-                sv[i] = sacc[i] + img[(prow + 4 * h) * LROWP + 32 * wave + rr_base - kc];
+                sv[i] = sacc[i] + img[(prow + 4 * h) * LROWP + 32 * wl + rr_base - kc];
             }
             f32x16 cacc;
 #pragma unroll
@@ -383,13 +393,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], cacc);             // c2p of L(kt + 1)  [rr][query c]
             softmax_pv(sv, kt);
             band_store(c2p_l + c * LROW + (xr ^ 32), cacc);     // over the old high block (its gather is long retired)
+            if constexpr (STAG) wg_barrier_lds();               // end of P2: this half's image may be rewritten; V^T(kt) is retired
         };
+        if constexpr (STAG) { if (grp == 1) wg_barrier_lds(); } // the late half starts one phase later
         for (int kt = kt_a;;) {
             band_tile(kt, 0);
             if (++kt >= kt_b) break;
             band_tile(kt, 32);
             if (++kt >= kt_b) break;
         }
+        if constexpr (STAG) { if (grp == 0) wg_barrier_lds(); } // ... and the early half waits for it at the end
     }
 
     sat_tiles(kt_b, nkt, 0);
@@ -425,24 +438,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG> constexpr size_t wg_lds_bytes() {
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG> constexpr size_t wg_lds_bytes() {
     return KVG ? ((size_t)NW * 32 * LROW + 2 * 32 * (32 * (NW + 1) + 4)) * sizeof(float)
-               : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
+         : STAG ? ((size_t)NW * 32 * LROW + 2 * 32 * (32 * 5 + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T)
+                : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> raised{0};
-    constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG>();
+    constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
     static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG>, 64 * NW, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG>, 64 * NW, lds);
         fprintf(stderr, "[attn_wg] NW=%d lds=%zu bytes, occupancy API: %d workgroup(s) per CU\n", NW, lds, nb);
     }
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
     return nullptr;
 }
 
@@ -455,7 +469,11 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
     if (a.sel_b || a.stamps) return "attention(wg): no row selection / stamps in this kernel";
     if (dtype == GLC_DT_F32) {
         if (!a.split) return "attention(wg): the fp32 mode runs this kernel on split-f16 units only";
-        return (a.variant & 8) ? launch_wg<float, true, 8, true>(st, a) : launch_wg<float, true, 8, false>(st, a);
+        // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
+        static const bool stag_default = getenv("GLC_ATTN_STAG") != nullptr && atoi(getenv("GLC_ATTN_STAG")) != 0;
+        if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);
+        const bool stag = (a.variant & 16) ? true : ((a.variant & 32) ? false : stag_default);
+        return stag ? launch_wg<float, true, 8, false, true>(st, a) : launch_wg<float, true, 8, false, false>(st, a);
     }
     if (a.split) return "attention(wg): split operands belong to the fp32 mode";
     if (a.variant & 8) return dtype == GLC_DT_BF16 ? launch_wg<bf16_t, false, 4, true>(st, a) : launch_wg<f16_t, false, 4, true>(st, a);

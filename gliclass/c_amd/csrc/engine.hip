@@ -1104,7 +1104,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const LayerW& w = e->layers[0];
     const bool sp = e->dtype == GLC_F32;
     AttnArgs a{e->Qh, e->Kh, e->Vt, sp ? w.PKs : w.PK, sp ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 11; a.otab = e->otabs[Sp]; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring
+    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 59; a.otab = e->otabs[Sp]; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring; bits 4 / 5: wg kernel with / without the half-tile stagger
     hipStream_t st = e->stream;
     const bool wg = (variant & 4) != 0;                       // bit 2: the workgroup-shared kernel (attention_wg.hip)
     auto launch = [&]() -> const char* { return wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };

@@ -178,3 +178,32 @@ def test_multi_engine_session_on_one_gpu(workdir):
     if _lib.hip().glc_device_count() >= 2:                 # two DISTINCT devices when the box has them
         assert run("0,1", "1") == one
         assert sorted(run("0,1", "0")) == sorted(one)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prompt_first", [True, False])
+def test_reference_probe_through_the_launcher(workdir, prompt_first):
+    """The reference's own probe (convert_to_onnx.py:57-58; named fixture tests/golden/reference_probe.json) text-in -> printed
+    scores, against the oracle on the fixture's ids.  Its hub-stored golden logits are unreachable, so this pins the PATH the
+    probe takes (prompt, tokenizer, forward, sigmoid, printing) on a synthetic model, not the trained model's numbers."""
+    import oracle_c
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    probe = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_probe.json")))
+    cfg = dataclasses.replace(CONFIGS["tiny"], name="tiny-tok", vocab=6003, class_token_index=6001, text_token_index=6002)
+    w = weights.make_weights(cfg, 3)
+    blob = str(workdir / "tiny_tok_probe.glcw")
+    weights.write_blob(blob, cfg, w)
+    data = workdir / f"probe_{int(prompt_first)}.json"
+    data.write_text(json.dumps({"texts": [probe["text"]], "labels": [probe["labels"]], "same_labels": True,
+                                "classification_type": probe["classification_type"]}))
+    env = dict({k: v for k, v in os.environ.items() if not k.startswith("GLICLASS_")}, GLICLASS_THRESHOLD="0.0")     # default mode
+    r = subprocess.run([EXE, str(data), "true" if prompt_first else "false", str(workdir / "tok.json"), blob], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    ids = np.array([probe["ids_standin_tokenizer"]["prompt_first_true" if prompt_first else "prompt_first_false"]], np.int64)
+    assert int((ids == 6001).sum()) == len(probe["labels"])
+    lg = oracle_c.forward(cfg, w, ids, np.ones_like(ids))
+    want = {l: 1.0 / (1.0 + np.exp(-float(lg[0, j]))) for j, l in enumerate(probe["labels"])}
+    got = {m.group(1): float(m.group(2)) for m in re.finditer(r"  Text_0 Label: (\w+), Score: ([0-9.]+)", r.stdout)}
+    assert set(got) == set(want)
+    assert max(abs(got[k] - want[k]) for k in want) <= probe["tolerance_atol"] * 0.02       # 2e-5: %.6f printing + fp32, 50x inside the probe's atol

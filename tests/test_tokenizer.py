@@ -243,3 +243,27 @@ def test_grapheme_table_is_pinned_to_the_oracles_unicode_version(tok):
     assert tok.normalize("²᫨") == "2᫨" and tok.normalize("²᫏") == "2᫏"
     assert tok.normalize("²́") == "2"            # an old combining mark joins: the cluster is replaced as a whole (Rust quirk)
     assert tok.normalize("²ᫎ") == "2"            # U+1ACE: Unicode 14, joins
+
+
+def test_reference_probe_named_case(tok):
+    """The reference's own fixed probe (convert_to_onnx.py:57-58, test_onnx.py:64-65) as a NAMED case.  Its golden logits live on the HF
+    hub, so the numerical end stays unpinned; what is pinned here: the prompt the native prompt builder makes for it
+    (src/preprocessor.c:84-108) and the ids of the native tokenizer, equal to the Rust library's (tests/golden/reference_probe.json,
+    generated by oracle/gen_reference_probe.py)."""
+    from gliclass.c_amd import _lib
+    p = json.load(open(os.path.join(GOLD, "reference_probe.json")))
+    assert p["original_logits"] is None and p["tolerance_atol"] == 1e-3
+    L = _lib.model()
+    L.prepare_input.restype = C.c_void_p
+    L.prepare_input.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_bool]
+    labels = (C.c_char_p * len(p["labels"]))(*[l.encode() for l in p["labels"]])
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for key, flag in (("prompt_first_true", True), ("prompt_first_false", False)):
+        ptr = L.prepare_input(p["text"].encode(), labels, len(p["labels"]), flag)
+        built = C.string_at(ptr).decode("utf-8")
+        libc.free(ptr)
+        assert built == p["prompts"][key]
+        assert tok.encode(built, True) == p["ids_standin_tokenizer"][key]
+        ids, mask = tok.tokenize_inputs([built], 2048)
+        assert ids[0] == p["ids_standin_tokenizer"][key] and all(m == 1 for m in mask[0])

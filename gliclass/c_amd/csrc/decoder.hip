@@ -66,6 +66,47 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, T
     }
 }
 
+// fp32 rows in, group-split rows out (the A operand of the 256-tile GS GEMM)
+__global__ __launch_bounds__(256) void rmsnorm_gs_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, const float* __restrict__ w, float eps,
+                                                         int M, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* x = X + (size_t)row * H;
+    f16_t* y = Y + (size_t)row * 2 * H;
+    const int nch = H / 8;
+    float ss = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8), b = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += a[e] * a[e] + b[e] * b[e];
+    }
+    const float r = rsqrtf(wave_sum(ss) / (float)H + eps);
+    for (int ch = lane; ch < nch; ch += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8), b = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = w[ch * 8 + e] * (a[e] * r); o[4 + e] = w[ch * 8 + 4 + e] * (b[e] * r); }
+        gs_store8(y, ch * 8, o);
+    }
+}
+// F[m, i] = silu(GU[m, i]) * GU[m, I + i]: plain fp32 [gate | up] rows in, group-split rows out
+__global__ __launch_bounds__(256) void swiglu_gs_kernel(const float* __restrict__ GU, f16_t* __restrict__ F, size_t M, int I) {
+    const size_t nch = (size_t)I / 8, total = M * nch;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = idx / nch, ch = idx - m * nch;
+        const float* g = GU + m * 2 * I + ch * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(g + I), u1 = *reinterpret_cast<const f32x4*>(g + I + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = g0[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g0[e])) * u0[e];
+            o[4 + e] = g1[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-g1[e])) * u1[e];
+        }
+        gs_store8(F + m * 2 * I, (int)(ch * 8), o);
+    }
+}
+
 // In place on QKV [M, (nq + 2 nkv) d]: heads 0..nq-1 are Q (also scaled by qscale), nq..nq+nkv-1 are K.  cs = [Sp][d/2][2].
 template <typename T>
 __global__ __launch_bounds__(256) void rope_qk_kernel(T* __restrict__ QKV, const float* __restrict__ cs, int M, int Sp, int nq, int nkv,
@@ -192,6 +233,19 @@ const char* glc_launch_embed_plain(hipStream_t st, int dtype, const int64_t* ids
 const char* glc_launch_rmsnorm(hipStream_t st, int dtype, const void* X, void* Y, const float* w, float eps, int M, int H) {
     if (M <= 0 || !X || !Y || !w || H % 8) return "rmsnorm: bad args";
     DISPATCH_T(dtype, { hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((M + 3) / 4), dim3(256), 0, st, (const T*)X, (T*)Y, w, eps, M, H); });
+    return nullptr;
+}
+
+const char* glc_launch_rmsnorm_gs(hipStream_t st, const float* X, void* Y, const float* w, float eps, int M, int H) {
+    if (!X || !Y || !w || M <= 0 || H <= 0 || H % 32) return "rmsnorm_gs: bad args";
+    hipLaunchKernelGGL(rmsnorm_gs_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, w, eps, M, H);
+    return nullptr;
+}
+const char* glc_launch_swiglu_gs(hipStream_t st, const float* GU, void* F, size_t M, int I) {
+    if (!GU || !F || M == 0 || I <= 0 || I % 32) return "swiglu_gs: bad args";
+    const size_t total = M * ((size_t)I / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(swiglu_gs_kernel, dim3(grid), dim3(256), 0, st, GU, (f16_t*)F, M, I);
     return nullptr;
 }
 
@@ -329,7 +383,7 @@ template <typename T, int D, bool SPLIT = false>
 __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const T* __restrict__ Qf, const T* __restrict__ Kf, const T* __restrict__ Vt,
                                                                const float* __restrict__ kbias, const int* __restrict__ klen,
                                                                const int* __restrict__ kfirst_, T* __restrict__ CTX, int B, int Sp, int nq,
-                                                               int nkv, int causal) {
+                                                               int nkv, int causal, int ctx_gs) {
     static_assert(!SPLIT || sizeof(T) == 4, "split units live in the fp32 layouts");
     typedef typename GqaFrag<SPLIT, T>::type frag_t;
     constexpr int NS = D / 16, ND = D / 32;
@@ -453,6 +507,17 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int a = 0; a < ND; ++a) store_acc32_wide<T>(o[a], inv, out + 32 * a, h);      // 16-byte stores via v_permlane32_swap (glc_common.h)
+    } else if (ctx_gs) {
+        // group-split context rows: block a of this head is group hq * D/32 + a of the row; hi = f16(v), lo = f16(v - hi)
+        f16_t* row = reinterpret_cast<f16_t*>(CTX) + ((size_t)b * Sp + q0 + c) * 2 * ((size_t)nq * D) + (size_t)(hq * (D / 32)) * 64;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            f32x16 lo;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const float v = o[a][i] * inv; lo[i] = v - (float)(f16_t)v; }
+            store_acc32_wide<f16_t>(o[a], inv, row + 64 * a, h);
+            store_acc32_wide<f16_t>(lo, 1.0f, row + 64 * a + 32, h);
+        }
     } else {
 #pragma unroll
         for (int a = 0; a < ND; ++a)
@@ -470,11 +535,11 @@ template <typename T, bool SPLIT = false> const char* launch_layout_t(hipStream_
     return nullptr;
 }
 template <typename T, bool SPLIT = false> const char* launch_gqa_t(hipStream_t st, const void* Qf, const void* Kf, const void* Vt, const float* kbias, const int* klen,
-                                               const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal) {
+                                               const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal, int ctx_gs = 0) {
     const int nt = Sp / 32, nqb = (nt + 3) / 4, per = (nq / nkv) * nqb, bg8 = (B * nkv + 7) / 8 * 8;
     const dim3 grid(per * bg8), block(256);
-    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
-    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal);
+    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal, ctx_gs);
+    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal, ctx_gs);
     return nullptr;
 }
 
@@ -492,12 +557,12 @@ const char* glc_launch_qkv_layout(hipStream_t st, int dtype, const void* QKV, co
 
 // MFMA grouped-query attention on the fragment-major operands written by glc_launch_qkv_layout.  CTX [B*Sp, nq*d] row-major.
 const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void* Qf, const void* Kf, const void* Vt, const float* kbias,
-                                          const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal) {
+                                          const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal, int ctx_gs) {
     if (!Qf || !Kf || !Vt || !kbias || !klen || !kfirst || !CTX || B <= 0 || Sp <= 0 || Sp % 64 || nq <= 0 || nkv <= 0 || nq % nkv ||
         (d != 64 && d != 128))
         return "attention_gqa_mfma: bad args";
     if (dtype == GLC_DT_BF16) return launch_gqa_t<bf16_t>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);
     if (dtype == GLC_DT_F16) return launch_gqa_t<f16_t>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);
-    if (dtype == GLC_DT_F32) return launch_gqa_t<float, true>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal);   // split-f16 units
+    if (dtype == GLC_DT_F32) return launch_gqa_t<float, true>(st, Qf, Kf, Vt, kbias, klen, kfirst, CTX, B, Sp, nq, nkv, d, causal, ctx_gs);   // split-f16 units
     return "attention_gqa_mfma: bad dtype";
 }

@@ -290,8 +290,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
 // GEMM launches of the forward carry the engine's split-K workspace (used only when a shape has too few tiles, gemm.hip)
 static bool presplit_weight(const glc_engine* e, int dt, const void* W) {
     if (!e->w_presplit || dt != GLC_F32) return false;
-    if (W == e->headw[0] || W == e->headw[2]) return true;                       // head projectors (their second group W2 goes with them)
-    return e->cfg.backbone != GLC_BACKBONE_DECODER;                              // encoder layer weights of the fp32 mode
+    return true;                                                                 // head projectors and every layer weight of the fp32 mode
 }
 const char* launch_gemm_auto(glc_engine* e, int dt, int epi, GemmArgs a) {
     a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes; a.w_presplit = presplit_weight(e, dt, a.W);
@@ -324,31 +323,44 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     const float qscale = 1.4426950408889634f / sqrtf((float)d);         // Q2:186 scaling, times log2(e) for the exp2 softmax
     const bool mfma = (dt != GLC_F32 || e->dec_split) && e->attn_impl != 1;   // flash-style MFMA kernel (fp32 mode: on split-f16 units); impl 1 / native fp32: straightforward kernel
+    // group-split pipeline of the fp32 mode (see run_forward): the GEMM A operands (RMSNorm outputs, context rows, SwiGLU output) are
+    // written as [32 hi | 32 lo] groups by their producers and every projection runs on the 256-tile LDS-DMA kernel; the residual
+    // stream X, the fused QKV rows (RoPE / layout pass) and the [gate | up] rows stay plain fp32
+    bool gs = false;
+    if (dt == GLC_F32 && e->gs_mode > 0 && e->w_presplit && e->dec_split && mfma && !e->keep_hidden && H % 256 == 0 && (2 * I) % 256 == 0 &&
+        NQKV % 256 == 0 && NQ % 32 == 0 && I % 32 == 0) {
+        GemmArgs t; t.Mpad = Mpad; t.N = H; t.K = H;
+        gs = e->gs_mode == 2 || !glc_gemm_small_m(t);
+    }
+    e->last_gs = gs;
     void *X = e->X, *Xn = e->X2;
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = e->dlayers[l];
-        { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln1, c.ln_eps, M, H), false); }                        // Q2:280
+        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln1, c.ln_eps, M, H)
+                                    : glc_launch_rmsnorm(st, dt, X, e->H1, w.ln1, c.ln_eps, M, H), false); }                        // Q2:280
         GemmArgs g;
-        g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H;
-        { Prof p(e, PC_QKV); KCHK(launch_gemm_auto(e, dt, EPI_BIAS, g), false);                                           // Q2:206-208
+        g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H; g.gs_c_plain = 1;
+        { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
           if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
           else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
         { Prof p(e, PC_ATTN);
-          if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal), false);
+          if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal, gs ? 1 : 0), false);
           else KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
         GemmArgs o;
-        o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ;
-        { Prof p(e, PC_ATTN_OUT); KCHK(launch_gemm_auto(e, dt, EPI_RESID, o), false); }                                   // Q2:233, :291
+        o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ; o.gs_resid_plain = 1;
+        { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }   // Q2:233, :291
         std::swap(X, Xn);
-        { Prof p(e, PC_LN); KCHK(glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
+        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln2, c.ln_eps, M, H)
+                                    : glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
         { Prof p(e, PC_FFN1);                                                                                                  // Q2:47 silu(gate) * up
           if (e->fused_swiglu) { f1.C = e->FF; KCHK(glc_launch_gemm256s(st, dt, EPI_SWIGLU, f1), false); }
+          else if (gs) { f1.gs_c_plain = 1; KCHK(glc_launch_gemm256s_gs(st, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu_gs(st, (const float*)e->GU, e->FF, (size_t)M, I), false); }
           else { KCHK(launch_gemm_auto(e, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); } }
         GemmArgs f2;
-        f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        { Prof p(e, PC_FFN2); KCHK(launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
+        f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I; f2.gs_resid_plain = 1;
+        { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         std::swap(X, Xn);
         if (e->keep_hidden && l + 1 < L)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
@@ -566,6 +578,13 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
                 lok = upload_as(e, t[9], (size_t)I * H, w.Wgu, staging) && upload_as(e, t[10], (size_t)I * H, (char*)w.Wgu + (size_t)I * H * es, staging);
             }
             if (!lok) break;
+            if (e->w_presplit && e->dtype == GLC_F32) {     // group-split weight rows (the operand image of both split-f16 GEMM kernels)
+                const char* pm = glc_launch_presplit(e->stream, w.Wqkv, NQKV * H);
+                if (!pm) pm = glc_launch_presplit(e->stream, w.Wo, (size_t)H * NQ);
+                if (!pm) pm = glc_launch_presplit(e->stream, w.Wgu, 2 * (size_t)I * H);
+                if (!pm) pm = glc_launch_presplit(e->stream, w.Wd, (size_t)H * I);
+                if (pm) { set_err(pm); lok = false; break; }
+            }
             for (size_t i = 0; i < NQ; ++i) bqkv[i] = t[2][i];
             for (size_t i = 0; i < NKV; ++i) { bqkv[NQ + i] = t[4][i]; bqkv[NQ + NKV + i] = t[6][i]; }
             w.bqkv = upload_f32(e, bqkv.data(), NQKV);

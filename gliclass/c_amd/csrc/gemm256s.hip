@@ -222,9 +222,15 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
                 if constexpr (GS) {
                     const int n = n0 + wn * 64 + g8 * 8;
-                    const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
-                    r[k] = *reinterpret_cast<const vec8T*>(rp);
-                    rl[k] = *reinterpret_cast<const vec8T*>(rp + 32);
+                    if (p.gs_resid_plain) {      // plain fp32 residual row: its 8 floats ride in the two 16-byte registers
+                        const float* rp = reinterpret_cast<const float*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * N + n;
+                        r[k] = __builtin_bit_cast(vec8T, *reinterpret_cast<const f32x4*>(rp));
+                        rl[k] = __builtin_bit_cast(vec8T, *reinterpret_cast<const f32x4*>(rp + 4));
+                    } else {
+                        const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
+                        r[k] = *reinterpret_cast<const vec8T*>(rp);
+                        rl[k] = *reinterpret_cast<const vec8T*>(rp + 32);
+                    }
                 } else {
                     r[k] = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) +
                                                            (size_t)(m0 + wm * 128 + c * 32 + row) * N + n0 + wn * 64 + g8 * 8);
@@ -267,8 +273,14 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 const int m = m0 + wm * 128 + c * 32 + row;
                 const int n = n0 + wn * 64 + g8 * 8;
                 if (EPI == EPI_RESID) {
+                    if (GS && p.gs_resid_plain) {
+                        const f32x4 ra = __builtin_bit_cast(f32x4, rcur[k]), rb = __builtin_bit_cast(f32x4, rcur_lo[GS ? k : 0]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += GS ? (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e] : (float)rcur[k][e];
+                        for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += GS ? (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e] : (float)rcur[k][e];
+                    }
                 }
                 vec8T o, ol;
 #pragma unroll
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                         } else *reinterpret_cast<vec8T*>(base + off) = o;
                     }
                 } else if constexpr (GS) {
-                    if (EPI == EPI_RESID) {         // plain fp32 row (LayerNorm input)
+                    if (EPI == EPI_RESID || p.gs_c_plain) {         // plain fp32 row (LayerNorm input; decoder: QKV / gate|up rows)
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};

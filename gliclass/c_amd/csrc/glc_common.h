@@ -138,6 +138,23 @@ __device__ __forceinline__ f32x2 glc_gelu2(f32x2 x) {
     return x * r;
 }
 
+// Group-split ("GS") rows of the fp32 mode (glc_kernels.h): element e of a row lives at halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
+typedef __attribute__((ext_vector_type(8))) _Float16 gs_h8;
+__device__ __forceinline__ void gs_store8(f16_t* row, int e0, const float (&v)[8]) {      // e0 % 8 == 0
+    gs_h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; lo[e] = (f16_t)(v[e] - (float)h); }
+    f16_t* p = row + (e0 >> 5) * 64 + (e0 & 31);
+    *reinterpret_cast<gs_h8*>(p) = hi;
+    *reinterpret_cast<gs_h8*>(p + 32) = lo;
+}
+__device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]) {
+    const f16_t* p = row + (e0 >> 5) * 64 + (e0 & 31);
+    const gs_h8 hi = *reinterpret_cast<const gs_h8*>(p), lo = *reinterpret_cast<const gs_h8*>(p + 32);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)hi[e] + (float)lo[e];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

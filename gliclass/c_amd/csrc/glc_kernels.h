@@ -29,6 +29,9 @@ struct GemmArgs {
     // gemm_nt (128-tile) split-K for small M: the K loop is cut into `ksplit` parts (grid.z), each writes its fp32 partial tile to
     // ws[z][Mpad][N]; a second pass sums the parts in a fixed order and applies the epilogue.  ws_bytes = capacity of ws.
     float* ws = nullptr; size_t ws_bytes = 0;
+    // gemm256s on group-split operands (glc_launch_gemm256s_gs): EPI_BIAS / EPI_GELU write C as plain fp32 rows instead of GS rows;
+    // EPI_RESID reads its residual as plain fp32 rows instead of GS rows (decoder backbone: the residual stream itself)
+    int gs_c_plain = 0, gs_resid_plain = 0;
 };
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);
@@ -152,6 +155,9 @@ const char* glc_launch_head_gather_sel(hipStream_t st, int dtype, const void* Xs
 const char* glc_launch_embed_plain(hipStream_t st, int dtype, const int64_t* ids, const int64_t* mask, const void* table, void* X,
                                    float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id);
 // Y = w * X * rsqrt(mean(X^2) + eps) row-wise
+// (glc_launch_rmsnorm_gs: fp32 X in, group-split Y out; glc_launch_swiglu_gs: plain fp32 [gate | up] rows in, group-split F out)
+const char* glc_launch_rmsnorm_gs(hipStream_t st, const float* X, void* Y, const float* w, float eps, int M, int H);
+const char* glc_launch_swiglu_gs(hipStream_t st, const float* GU, void* F, size_t M, int I);
 const char* glc_launch_rmsnorm(hipStream_t st, int dtype, const void* X, void* Y, const float* w, float eps, int M, int H);
 // in-place rotate-half RoPE on the Q and K heads of QKV [M, (nq+2nkv) d]; cs = [Sp][d/2][cos,sin]; Q additionally * qscale
 const char* glc_launch_rope_qk(hipStream_t st, int dtype, void* QKV, const float* cs, int M, int Sp, int nq, int nkv, int d, float qscale);
@@ -163,8 +169,9 @@ const char* glc_launch_attention_gqa(hipStream_t st, int dtype, int impl, const 
 // 16-bit MFMA path: RoPE + scale + fragment-major Q / K / V^T (layouts in decoder.hip), then the flash-style kernel
 const char* glc_launch_qkv_layout(hipStream_t st, int dtype, const void* QKV, const float* cs, void* Qf, void* Kf, void* Vt, int B, int Sp,
                                   int nq, int nkv, int d, float qscale);
+// ctx_gs (fp32 mode only): write the context rows in the group-split format
 const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void* Qf, const void* Kf, const void* Vt, const float* kbias,
-                                          const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal);
+                                          const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal, int ctx_gs = 0);
 
 // dtype conversion fp32 -> T (weights upload), n elements
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);

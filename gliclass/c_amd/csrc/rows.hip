@@ -59,21 +59,6 @@ __device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restri
 // hi = f16(x), lo = f16(x - hi) — the row image the split-f16 GEMMs consume (gemm.hip presplit weights use the same format), so the
 // 256-tile LDS-DMA GEMM can fetch hi and lo parts of a 32-deep K step as plain 64-byte row pieces.  Element e of a row lives at
 // halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
-typedef __attribute__((ext_vector_type(8))) _Float16 gs_h8;
-__device__ __forceinline__ void gs_store8(f16_t* row, int e0, const float (&v)[8]) {      // e0 % 8 == 0
-    gs_h8 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; lo[e] = (f16_t)(v[e] - (float)h); }
-    f16_t* p = row + (e0 >> 5) * 64 + (e0 & 31);
-    *reinterpret_cast<gs_h8*>(p) = hi;
-    *reinterpret_cast<gs_h8*>(p + 32) = lo;
-}
-__device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]) {
-    const f16_t* p = row + (e0 >> 5) * 64 + (e0 & 31);
-    const gs_h8 hi = *reinterpret_cast<const gs_h8*>(p), lo = *reinterpret_cast<const gs_h8*>(p + 32);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)hi[e] + (float)lo[e];
-}
 // LayerNorm of one fp32 row by one wave, output in the GS format (8 elements per lane and chunk)
 template <bool MASKED>
 __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_t* __restrict__ y, const float* __restrict__ gamma,

@@ -218,3 +218,30 @@ def test_c5_full_size_decoder(weights_for, c_generated_weights):
             assert np.abs(sig(got) - sig(ref)).max() <= 6e-2               # bf16 envelope (TOL_PROB)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("cname", ["dec-tiny", "dec-mini"])
+def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_for):
+    """fp32 mode of the decoder backbone, the two activation formats (see test_gpu_parity.py::test_group_split_pipeline_...): group-split
+    RMSNorm / context / SwiGLU rows + 256-tile GEMMs (plain fp32 residual stream, QKV rows and [gate | up] rows) against the plain
+    fp32 rows + 128-tile split GEMMs and against the oracle."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w = weights_for(cname)
+    eng = Engine(cfg, w, dtype="f32")
+    try:
+        for (B, S, Cn, lpr, seed) in ((3, 200, 3, [3, 0, 2], 71), (2, 700, 4, None, 72), (5, 64, 2, None, 73)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=seed, ragged=True, labels_per_row=lpr)
+            ref = oracle_c.forward(cfg, w, ids, mask)
+            eng.set_group_split(0)
+            plain = eng.forward(ids, mask)
+            assert not eng.last_group_split()
+            eng.set_group_split(2)
+            gs = eng.forward(ids, mask)
+            assert eng.last_group_split()
+            assert np.isfinite(gs).all()
+            assert np.abs(sig(gs) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
+            assert np.abs(sig(gs) - sig(plain)).max() <= 1e-4, (B, S)
+    finally:
+        eng.close()

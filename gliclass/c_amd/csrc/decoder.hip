@@ -128,15 +128,19 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(T* __restrict__ QKV, const
 }
 
 // F[m, i] = silu(GU[m, i]) * GU[m, I + i]
+// inter = 1: the [gate | up] columns interleave 16 gate / 16 up features (the fused weight layout of the SwiGLU GEMM epilogue,
+// engine.hip): feature i's gate is column 32 (i / 16) + i % 16, its up column 16 further on
 template <typename T>
-__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ GU, T* __restrict__ F, size_t M, int I) {
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ GU, T* __restrict__ F, size_t M, int I, int inter) {
     typedef typename Vec16<T>::type vecT;
     constexpr int VEC = Vec16<T>::N;
     const size_t nch = (size_t)I / VEC, total = M * nch;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t m = idx / nch, ch = idx - m * nch;
-        const vecT g = *reinterpret_cast<const vecT*>(GU + m * 2 * I + ch * VEC);
-        const vecT u = *reinterpret_cast<const vecT*>(GU + m * 2 * I + I + ch * VEC);
+        const size_t f0 = ch * VEC;
+        const size_t gcol = inter ? 32 * (f0 / 16) + f0 % 16 : f0, ucol = inter ? gcol + 16 : (size_t)I + f0;
+        const vecT g = *reinterpret_cast<const vecT*>(GU + m * 2 * I + gcol);
+        const vecT u = *reinterpret_cast<const vecT*>(GU + m * 2 * I + ucol);
         vecT o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -255,13 +259,13 @@ const char* glc_launch_rope_qk(hipStream_t st, int dtype, void* QKV, const float
     return nullptr;
 }
 
-const char* glc_launch_swiglu(hipStream_t st, int dtype, const void* GU, void* F, size_t M, int I) {
+const char* glc_launch_swiglu(hipStream_t st, int dtype, const void* GU, void* F, size_t M, int I, int inter) {
     if (M == 0 || I <= 0 || I % 8 || !GU || !F) return "swiglu: bad args";
     DISPATCH_T(dtype, {
         const size_t total = M * ((size_t)I / Vec16<T>::N);
         size_t blocks = (total + 255) / 256;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        hipLaunchKernelGGL(swiglu_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)GU, (T*)F, M, I);
+        hipLaunchKernelGGL(swiglu_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)GU, (T*)F, M, I, inter);
     });
     return nullptr;
 }

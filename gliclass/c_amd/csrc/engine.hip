@@ -185,7 +185,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
             dfree(e, e->Kh); e->Kh = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Kh) return false;
             dfree(e, e->Vt); e->Vt = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Vt) return false;
         }
-        if (!e->fused_swiglu) { dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false; }
+        if (!e->fused_swiglu || e->dtype == GLC_F32) { dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
         e->capM = Mpad;
@@ -355,7 +355,10 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
         { Prof p(e, PC_FFN1);                                                                                                  // Q2:47 silu(gate) * up
-          if (e->fused_swiglu) { f1.C = e->FF; KCHK(glc_launch_gemm256s(st, dt, EPI_SWIGLU, f1), false); }
+          if (e->fused_swiglu && gs) { f1.C = e->FF; KCHK(glc_launch_gemm256s_gs(st, EPI_SWIGLU, f1), false); }
+          else if (e->fused_swiglu && dt == GLC_F32) {      // small forward of the fp32 mode: plain rows, interleaved [gate | up] columns
+              KCHK(launch_gemm_auto(e, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I, 1), false); }
+          else if (e->fused_swiglu) { f1.C = e->FF; KCHK(glc_launch_gemm256s(st, dt, EPI_SWIGLU, f1), false); }
           else if (gs) { f1.gs_c_plain = 1; KCHK(glc_launch_gemm256s_gs(st, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu_gs(st, (const float*)e->GU, e->FF, (size_t)M, I), false); }
           else { KCHK(launch_gemm_auto(e, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); } }
         GemmArgs f2;
@@ -552,8 +555,9 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
         if (!e->emb || !upload_as(e, tensors[0], (size_t)c.vocab * H, e->emb, staging)) break;
         e->dlayers.resize(L);
         // SwiGLU in the epilogue of the staggered 256-tile GEMM when the shapes allow it (16-bit operands)
-        e->fused_swiglu = e->dtype != GLC_F32 && (2 * I) % 256 == 0 && H % 32 == 0 && I % 16 == 0 && glc_gemm_use_stagger() &&
-                          getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
+        // (fp32 mode: the group-split 256-tile GEMM has the same epilogue; its small-forward fallback un-fuses on the interleaved columns)
+        e->fused_swiglu = (e->dtype != GLC_F32 || (e->w_presplit && e->dec_split && H % 256 == 0)) && (2 * I) % 256 == 0 && H % 32 == 0 && I % 16 == 0 &&
+                          glc_gemm_use_stagger() && getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
         std::vector<float> bqkv(NQKV), gu_host(e->fused_swiglu ? 2 * (size_t)I * H : 0);
         bool lok = true;
         for (int l = 0; l < L && lok; ++l) {

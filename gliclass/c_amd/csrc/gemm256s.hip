@@ -199,6 +199,15 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { o[e] = (T)lo[e]; o[4 + e] = (T)hi[e]; }
                 const int m = m0 + wm * 128 + c * 32 + row;
+                if constexpr (GS) {         // group-split output row of I features
+                    vec8T ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ol[e] = (T)(lo[e] - (float)o[e]); ol[4 + e] = (T)(hi[e] - (float)o[4 + e]); }
+                    const int f = (n0 >> 1) + wn * 32 + g4 * 8;
+                    T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * I + (f >> 5) * 64 + (f & 31);
+                    *reinterpret_cast<vec8T*>(cp) = o;
+                    *reinterpret_cast<vec8T*>(cp + 32) = ol;
+                } else
                 *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * I + (n0 >> 1) + wn * 32 + g4 * 8) = o;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -394,7 +403,7 @@ static bool gemm256s_supported(int dtype, const GemmArgs& a) {
 bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi) {
     if (!(a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 32 == 0)) return false;
     if (epi == EPI_QKV) return a.H % 256 == 0 && a.N == 3 * a.H && a.Sp % 64 == 0 && a.Sp >= 64 && a.nh * 64 == a.H;
-    return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID;
+    return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_SWIGLU;
 }
 
 // fp32 mode on group-split operands (see the kernel header): T = f16 halves, K' = 3K/32 steps.
@@ -409,6 +418,7 @@ const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a) {
         case EPI_BIAS: return launch_e<f16_t, EPI_BIAS, false, true>(st, a, 0, ntn);
         case EPI_GELU: return launch_e<f16_t, EPI_GELU, false, true>(st, a, 0, ntn);
         case EPI_RESID: return launch_e<f16_t, EPI_RESID, false, true>(st, a, 0, ntn);
+        case EPI_SWIGLU: return a.bias ? "gemm256s(gs): the SwiGLU epilogue takes no bias" : launch_e<f16_t, EPI_SWIGLU, false, true>(st, a, 0, ntn);
         case EPI_QKV: {
             const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
             const char* m = launch_e<f16_t, EPI_QKV, false, true>(st, a, nq, nqk - nq);

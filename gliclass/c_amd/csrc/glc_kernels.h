@@ -162,7 +162,7 @@ const char* glc_launch_rmsnorm(hipStream_t st, int dtype, const void* X, void* Y
 // in-place rotate-half RoPE on the Q and K heads of QKV [M, (nq+2nkv) d]; cs = [Sp][d/2][cos,sin]; Q additionally * qscale
 const char* glc_launch_rope_qk(hipStream_t st, int dtype, void* QKV, const float* cs, int M, int Sp, int nq, int nkv, int d, float qscale);
 // F[m,i] = silu(GU[m,i]) * GU[m,I+i]
-const char* glc_launch_swiglu(hipStream_t st, int dtype, const void* GU, void* F, size_t M, int I);
+const char* glc_launch_swiglu(hipStream_t st, int dtype, const void* GU, void* F, size_t M, int I, int inter = 0);   // inter: 16 gate / 16 up interleaved columns
 // grouped-query attention on the row-major fused QKV (Q pre-scaled by log2e/sqrt(d)); CTX [B*Sp, nq*d]; impl 1 = straightforward
 const char* glc_launch_attention_gqa(hipStream_t st, int dtype, int impl, const void* QKV, const float* kbias, const int* klen, void* CTX,
                                      int B, int Sp, int nq, int nkv, int d, int causal);

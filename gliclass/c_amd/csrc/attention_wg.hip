@@ -61,15 +61,19 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
 // 4 waves) and run the band loop HALF A TILE apart: the tile body is two phases, P1 = [S^T, p2c MFMAs, image stores] and P2 = [gathers,
 // softmax, P.V, next c2p block], with one workgroup barrier after each; the late half enters the loop one barrier later, so on every SIMD
 // one wave is in the matrix-heavy phase while its partner is in the VALU / LDS-heavy one (the staggered-wave-group idea of gemm256s.hip).
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false>
+// VGL (split units, NW = 4): only K goes through the ring (8 KiB per tile = two DMA pieces per wave); V^T fragments are loaded per wave
+// from global memory.  80 KiB of LDS: TWO workgroups of four waves per CU, i.e. the two waves of a SIMD belong to different workgroups.
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     static_assert(!STAG || (NW == 8 && !KVG), "the stagger pairs the two 4-wave halves of an 8-wave workgroup");
+    static_assert(!VGL || (SPLIT && NW == 4 && !KVG && !STAG), "V^T from global: the 4-wave split-unit variant");
     static_assert(!SPLIT || sizeof(T) == 4, "split operands live in the fp32 layouts");
     static_assert(SPLIT || sizeof(T) == 2, "16-bit operands or split-f16 units");
     typedef typename WgFrag<SPLIT, T>::type frag_t;
     constexpr int UNITB = 512 * (int)sizeof(T);      // bytes of one fragment unit (64 lanes x 8 elements)
     constexpr int TILEB = 4 * UNITB;                 // one K tile, or one V^T tile
-    constexpr int NPIECE = 2 * TILEB / 1024;         // 1-KiB DMA pieces per key tile (K then V^T): 8 or 16 = 2 per wave
+    constexpr int NPIECE = (VGL ? 1 : 2) * TILEB / 1024;     // 1-KiB DMA pieces per key tile (K then V^T, or K only): 2 per wave
+    constexpr int SLOTB = (VGL ? 1 : 2) * TILEB;             // bytes of one ring slot
     static_assert(KVG || NPIECE == 2 * NW, "two DMA pieces per wave and tile");
     constexpr int NSH = STAG ? 4 : NW;               // waves that share one p2c image
     constexpr int NIMG = (KVG || STAG) ? 2 : 1;      // images: KVG alternates two, STAG keeps one per half
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(Kg + (size_t)t * TILEB + s * UNITB + lane * (UNITB / 64));
         } else {
-            const unsigned char* tile = kv_ring + (size_t)(t % 3) * 2 * TILEB;
+            const unsigned char* tile = kv_ring + (size_t)(t % 3) * SLOTB;
 #pragma unroll
             for (int s = 0; s < 4; ++s) f[s] = ring_unit(tile + s * UNITB);
         }
@@ -165,14 +169,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     // LDS-DMA of key tile t into ring slot t % 3: piece p = 2 wave + i is 1 KiB of [K tile | V^T tile]
     auto dma_tile = [&](int t) {
         if constexpr (KVG) return;
-        unsigned char* slot = kv_ring + (size_t)(t % 3) * 2 * TILEB;
+        unsigned char* slot = kv_ring + (size_t)(t % 3) * SLOTB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = 2 * wave + i;
             if constexpr (SPLIT) {
                 // piece p = (unit `wave` of [K | V^T], part i): every lane fetches the hi (i = 0) or lo (i = 1) 16 bytes of ITS 32-byte
                 // entry, so the unit lands as [64 x hi | 64 x lo] (the per-lane source address makes the DMA a gather)
-                const unsigned char* ubase = wave < 4 ? Kg + (size_t)t * TILEB + wave * UNITB : Vg + (size_t)t * TILEB + (wave - 4) * UNITB;
+                const unsigned char* ubase = (VGL || wave < 4) ? Kg + (size_t)t * TILEB + wave * UNITB : Vg + (size_t)t * TILEB + (wave - 4) * UNITB;
                 glds16(ubase + lane * 32 + i * 16, slot + p * 1024);
             } else {
                 const unsigned char* src = (p < NPIECE / 2 ? Kg + (size_t)t * TILEB + p * 1024 : Vg + (size_t)t * TILEB + (p - NPIECE / 2) * 1024) + lane * 16;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     auto softmax_pv = [&](float (&sv)[16], int kt) {
         const int k0 = kt * 32;
         frag_t vt[2][2];
-        if constexpr (KVG) {
+        if constexpr (KVG || VGL) {
             const unsigned char* vtile = Vg + (size_t)kt * TILEB + lane * (UNITB / 64);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
                 vt[1][t] = *reinterpret_cast<const frag_t*>(vtile + (2 + t) * UNITB);
             }
         } else {
-            const unsigned char* vtile = kv_ring + (size_t)(kt % 3) * 2 * TILEB + TILEB;
+            const unsigned char* vtile = kv_ring + (size_t)(kt % 3) * SLOTB + TILEB;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 vt[0][t] = ring_unit(vtile + t * UNITB);
@@ -438,25 +442,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG> constexpr size_t wg_lds_bytes() {
-    return KVG ? ((size_t)NW * 32 * LROW + 2 * 32 * (32 * (NW + 1) + 4)) * sizeof(float)
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG, bool VGL> constexpr size_t wg_lds_bytes() {
+    return VGL ? ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 4 * 512 * sizeof(T) :
+           KVG ? ((size_t)NW * 32 * LROW + 2 * 32 * (32 * (NW + 1) + 4)) * sizeof(float)
          : STAG ? ((size_t)NW * 32 * LROW + 2 * 32 * (32 * 5 + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T)
                 : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> raised{0};
-    constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG>();
+    constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG, VGL>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
     static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG>, 64 * NW, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL>, 64 * NW, lds);
         fprintf(stderr, "[attn_wg] NW=%d lds=%zu bytes, occupancy API: %d workgroup(s) per CU\n", NW, lds, nb);
     }
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
     return nullptr;
 }
 
@@ -472,6 +477,7 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
         // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
         static const bool stag_default = getenv("GLC_ATTN_STAG") != nullptr && atoi(getenv("GLC_ATTN_STAG")) != 0;
         if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);
+        if (a.variant & 1) return launch_wg<float, true, 4, false, false, true>(st, a);      // diagnostic: 4 waves, K ring only, two workgroups per CU
         const bool stag = (a.variant & 16) ? true : ((a.variant & 32) ? false : stag_default);
         return stag ? launch_wg<float, true, 8, false, true>(st, a) : launch_wg<float, true, 8, false, false>(st, a);
     }

@@ -37,6 +37,7 @@
 #include "glc_cpus.h"
 #include "glc_json.h"
 #include "glc_unicode_tables.h"
+#include "glc_bpe_tables.h"
 #include "tokenizers_c.h"
 
 /* ---------------------------------------------------------------- small utilities */
@@ -189,7 +190,10 @@ static size_t grapheme_end(const unsigned char* s, size_t i, size_t n) {
 
 /* ---------------------------------------------------------------- tokenizer object */
 
-enum { N_STRIP = 1, N_PRECOMPILED, N_REPLACE_LIT, N_REPLACE_RUN, N_LOWERCASE, N_PREPEND };
+enum { N_STRIP = 1, N_PRECOMPILED, N_REPLACE_LIT, N_REPLACE_RUN, N_LOWERCASE, N_PREPEND, N_NFC };
+enum { MODEL_UNIGRAM = 0, MODEL_BPE = 1 };
+enum { BLRE_NONE = 0, BLRE_GPT2 = 1, BLRE_QWEN = 2 };        /* which split regex runs before the byte-level mapping */
+typedef struct { uint64_t key; int32_t rank, merged; } bpe_merge;   /* open-addressing table: (left id << 32 | right id) -> rank, merged id */
 
 typedef struct {
     int kind;
@@ -226,6 +230,14 @@ typedef struct glc_tokenizer {
     tmpl_item* tmpl; size_t ntmpl; size_t tmpl_specials;
     size_t trunc_max; int trunc_left;
     int dec_metaspace;
+    /* byte-level BPE (GPT-2 / Qwen2 family) */
+    int model_kind;                           /* MODEL_UNIGRAM | MODEL_BPE */
+    bpe_merge* merges; size_t merge_cap;      /* power of two, key 0 = empty (id pair (0,0) is stored with key | 1<<63) */
+    int bpe_ignore_merges;
+    int pre_bytelevel, bl_regex, bl_prefix_space, dec_bytelevel;
+    uint16_t bl_cp[256];                      /* byte -> code point of its printable stand-in */
+    int32_t bl_char_id[256];                  /* vocabulary id of that one-character token (-1: absent) */
+    int16_t bl_byte_of[512];                  /* code point -> byte (-1: not a stand-in) */
     sbuf decoded;
 } glc_tokenizer;
 
@@ -455,6 +467,7 @@ static void norm_lowercase(const char* in, size_t n, sbuf* out) {
     }
 }
 
+static void norm_nfc(const char* in, size_t n, sbuf* out);
 /* Runs the whole chain; result in *a (b is scratch).  Returns 1 when the normalisers removed the START of the text (stripped
  * whitespace, a leading character rewritten to nothing): the piece then no longer begins at original offset 0, which is what
  * Metaspace's prepend_scheme "first" looks at. */
@@ -472,6 +485,7 @@ static int normalize_chain(const glc_tokenizer* tk, const char* in, size_t n, sb
             case N_REPLACE_RUN: norm_replace_run(st, a->s, a->len, b); break;
             case N_LOWERCASE: norm_lowercase(a->s, a->len, b); break;
             case N_PREPEND: if (a->len) sb_put(b, st->pat, st->patlen); sb_put(b, a->s, a->len); break;
+            case N_NFC: norm_nfc(a->s, a->len, b); break;
             default: sb_put(b, a->s, a->len);
         }
         sbuf t = *a; *a = *b; *b = t;
@@ -564,8 +578,10 @@ static void unigram_encode(const glc_tokenizer* tk, const char* s, size_t n, scr
 
 /* ---------------------------------------------------------------- pre-tokeniser + pieces */
 
+static void bpe_encode_piece(const glc_tokenizer* tk, const char* s, size_t n, scratch* sc, ivec* out);
 static void encode_text_piece(const glc_tokenizer* tk, const char* s, size_t n, int is_first, scratch* sc, ivec* out) {
     if (!n) return;
+    if (tk->model_kind == MODEL_BPE) { bpe_encode_piece(tk, s, n, sc, out); return; }
     if (!tk->has_metaspace) { unigram_encode(tk, s, n, sc, out); return; }
     sbuf* b = &sc->pre;
     sb_clear(b); sb_reserve(b, n * tk->ms_replen + tk->ms_replen);
@@ -691,6 +707,223 @@ static void encode_one(const glc_tokenizer* tk, const char* text, size_t len, in
     res->len = out.n;
 }
 
+/* ---------------------------------------------------------------- NFC (normalizer of the Qwen2 / GPT-style tokenizer.json files) */
+
+/* Data: glc_bpe_tables.h (scripts/gen_bpe_tables.py: unicodedata, checked code point by code point against the Rust library).
+ * Algorithm: UAX #15 — canonical decomposition (recursive, Hangul arithmetic), canonical ordering, canonical composition. */
+static int nfc_ccc(uint32_t c) {
+    if (c < 0x300) return 0;
+    size_t lo = 0, hi = sizeof(glc_nfc_ccc) / sizeof(glc_nfc_ccc[0]);
+    while (lo < hi) { size_t m = (lo + hi) / 2; if (glc_nfc_ccc[m].cp < c) lo = m + 1; else hi = m; }
+    return lo < sizeof(glc_nfc_ccc) / sizeof(glc_nfc_ccc[0]) && glc_nfc_ccc[lo].cp == c ? glc_nfc_ccc[lo].ccc : 0;
+}
+static const glc_decomp* nfc_decomp(uint32_t c) {
+    if (c < 0xC0) return NULL;
+    size_t lo = 0, hi = sizeof(glc_nfc_decomp) / sizeof(glc_nfc_decomp[0]);
+    while (lo < hi) { size_t m = (lo + hi) / 2; if (glc_nfc_decomp[m].cp < c) lo = m + 1; else hi = m; }
+    return lo < sizeof(glc_nfc_decomp) / sizeof(glc_nfc_decomp[0]) && glc_nfc_decomp[lo].cp == c ? &glc_nfc_decomp[lo] : NULL;
+}
+enum { H_SB = 0xAC00, H_LB = 0x1100, H_VB = 0x1161, H_TB = 0x11A7, H_LC = 19, H_VC = 21, H_TC = 28, H_NC = 21 * 28, H_SC = 19 * 21 * 28 };
+static void nfc_push_decomposed(uint32_t c, uint32_t** buf, size_t* n, size_t* cap) {
+    if (*n + 4 > *cap) { *cap = *cap ? *cap * 2 : 64; *buf = (uint32_t*)realloc(*buf, *cap * sizeof(uint32_t)); }
+    if (c >= H_SB && c < H_SB + H_SC) {
+        const uint32_t si = c - H_SB;
+        (*buf)[(*n)++] = H_LB + si / H_NC; (*buf)[(*n)++] = H_VB + (si % H_NC) / H_TC;
+        if (si % H_TC) (*buf)[(*n)++] = H_TB + si % H_TC;
+        return;
+    }
+    const glc_decomp* d = nfc_decomp(c);
+    if (!d) { (*buf)[(*n)++] = c; return; }
+    nfc_push_decomposed(d->a, buf, n, cap);
+    if (d->b) nfc_push_decomposed(d->b, buf, n, cap);
+}
+static uint32_t nfc_compose_pair(uint32_t a, uint32_t b) {
+    if (a >= H_LB && a < H_LB + H_LC && b >= H_VB && b < H_VB + H_VC) return H_SB + ((a - H_LB) * H_VC + (b - H_VB)) * H_TC;
+    if (a >= H_SB && a < H_SB + H_SC && (a - H_SB) % H_TC == 0 && b > H_TB && b < H_TB + H_TC) return a + (b - H_TB);
+    size_t lo = 0, hi = sizeof(glc_nfc_comp) / sizeof(glc_nfc_comp[0]);
+    while (lo < hi) {
+        size_t m = (lo + hi) / 2;
+        if (glc_nfc_comp[m].a < a || (glc_nfc_comp[m].a == a && glc_nfc_comp[m].b < b)) lo = m + 1; else hi = m;
+    }
+    return lo < sizeof(glc_nfc_comp) / sizeof(glc_nfc_comp[0]) && glc_nfc_comp[lo].a == a && glc_nfc_comp[lo].b == b ? glc_nfc_comp[lo].cp : 0;
+}
+static void norm_nfc(const char* in, size_t n, sbuf* out) {
+    size_t i = 0;
+    while (i < n && (unsigned char)in[i] < 0x80) ++i;
+    if (i == n) { sb_put(out, in, n); return; }                          /* ASCII is NFC */
+    uint32_t* d = NULL; size_t nd = 0, cap = 0;
+    const unsigned char* u = (const unsigned char*)in;
+    for (i = 0; i < n;) {
+        size_t adv; uint32_t c = u8_decode(u + i, n - i, &adv);
+        i += adv;
+        const glc_nfc_over* ov = NULL;
+        for (const glc_nfc_over* o = glc_nfc_override; o->cp; ++o) if (o->cp == c) { ov = o; break; }
+        if (ov) { for (int k = 0; k < 3 && ov->r[k]; ++k) nfc_push_decomposed(ov->r[k], &d, &nd, &cap); }
+        else nfc_push_decomposed(c, &d, &nd, &cap);
+    }
+    for (size_t k = 1; k < nd; ++k) {                                    /* canonical ordering: stable sort of each run of non-starters */
+        const int cc = nfc_ccc(d[k]);
+        if (!cc) continue;
+        size_t j = k; const uint32_t v = d[k];
+        while (j > 0) { const int pc = nfc_ccc(d[j - 1]); if (pc <= cc) break; d[j] = d[j - 1]; --j; }
+        d[j] = v;
+    }
+    if (nd) {                                                            /* canonical composition */
+        size_t starter = 0, comp = 1;
+        uint32_t sch = d[0];
+        int last = nfc_ccc(sch) ? 256 : 0;
+        for (size_t k = 1; k < nd; ++k) {
+            const uint32_t ch = d[k]; const int cc = nfc_ccc(ch);
+            const uint32_t c2 = nfc_compose_pair(sch, ch);
+            if (c2 && (last < cc || last == 0)) { d[starter] = c2; sch = c2; }
+            else { if (cc == 0) { starter = comp; sch = ch; } last = cc; d[comp++] = ch; }
+        }
+        nd = comp;
+    }
+    sb_reserve(out, nd * 4 + 4);
+    for (size_t k = 0; k < nd; ++k) { char t[4]; const size_t l = u8_encode(t, d[k]); sb_put(out, t, l); }
+    free(d);
+}
+
+/* ---------------------------------------------------------------- byte-level BPE */
+
+static int crange_lookup(const glc_crange* t, size_t n, uint32_t c) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) { size_t m = (lo + hi) / 2; if (t[m].hi < c) lo = m + 1; else hi = m; }
+    return lo < n && t[lo].lo <= c;
+}
+static int is_letter(uint32_t c) {                  /* \p{L} of the pre-tokenizer's regex engine (probed from the Rust library) */
+    if (c < 0x80) return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z');
+    return crange_lookup(glc_letter_ranges, sizeof(glc_letter_ranges) / sizeof(glc_letter_ranges[0]), c);
+}
+static int is_number(uint32_t c) {                  /* \p{N} */
+    if (c < 0x80) return c >= '0' && c <= '9';
+    return crange_lookup(glc_number_ranges, sizeof(glc_number_ranges) / sizeof(glc_number_ranges[0]), c);
+}
+static inline uint32_t cp_at(const unsigned char* s, size_t n, size_t i, size_t* adv) {
+    if (i >= n) { *adv = 0; return 0xFFFFFFFFu; }
+    return u8_decode(s + i, n - i, adv);
+}
+static inline int is_punct_class(uint32_t c) { return c != 0xFFFFFFFFu && !is_white_space(c) && !is_letter(c) && !is_number(c); }   /* [^\s\p{L}\p{N}] */
+
+/* End (byte offset) of the pre-token that starts at byte i, for the two split patterns byte-level BPE tokenizers ship with:
+ *   GPT-2 : 's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+
+ *   Qwen2 : (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
+ * Leftmost match, alternatives in order, greedy with backtracking (Oniguruma semantics); every position matches some alternative. */
+static size_t bl_next(int kind, const unsigned char* s, size_t n, size_t i) {
+    size_t a0, a1, a2;
+    const uint32_t c0 = cp_at(s, n, i, &a0);
+    const uint32_t c1 = cp_at(s, n, i + a0, &a1);
+    if (c0 == '\'') {                                                     /* contractions */
+        const uint32_t c2 = cp_at(s, n, i + a0 + a1, &a2);
+        const int ci = kind == BLRE_QWEN;
+        uint32_t l1 = c1, l2 = c2;
+        if (ci) { if (l1 >= 'A' && l1 <= 'Z') l1 += 32; if (l2 >= 'A' && l2 <= 'Z') l2 += 32; if (l1 == 0x17F) l1 = 's'; }
+        if (l1 == 's' || l1 == 't') return i + a0 + a1;
+        if ((l1 == 'r' && l2 == 'e') || (l1 == 'v' && l2 == 'e')) return i + a0 + a1 + a2;
+        if (l1 == 'm') return i + a0 + a1;
+        if (l1 == 'l' && l2 == 'l') return i + a0 + a1 + a2;
+        if (l1 == 'd') return i + a0 + a1;
+    }
+    if (kind == BLRE_QWEN) {
+        size_t j = i;                                                     /* [^\r\n\p{L}\p{N}]?\p{L}+ */
+        if (c0 != '\r' && c0 != '\n' && !is_letter(c0) && !is_number(c0) && is_letter(c1)) j = i + a0;
+        if (is_letter(cp_at(s, n, j, &a2))) {
+            while (j < n) { const uint32_t c = cp_at(s, n, j, &a2); if (!is_letter(c)) break; j += a2; }
+            return j;
+        }
+        if (is_number(c0)) return i + a0;                                 /* \p{N} */
+    } else {
+        size_t j = (c0 == ' ' && (is_letter(c1) || is_number(c1))) ? i + a0 : i;
+        const uint32_t f = cp_at(s, n, j, &a2);
+        if (is_letter(f)) { while (j < n) { const uint32_t c = cp_at(s, n, j, &a2); if (!is_letter(c)) break; j += a2; } return j; }
+        if (is_number(f)) { while (j < n) { const uint32_t c = cp_at(s, n, j, &a2); if (!is_number(c)) break; j += a2; } return j; }
+    }
+    {                                                                     /*  ?[^\s\p{L}\p{N}]+ ([\r\n]* for Qwen) */
+        size_t j = (c0 == ' ' && is_punct_class(c1)) ? i + a0 : i;
+        if (is_punct_class(cp_at(s, n, j, &a2))) {
+            while (j < n) { const uint32_t c = cp_at(s, n, j, &a2); if (!is_punct_class(c)) break; j += a2; }
+            if (kind == BLRE_QWEN) while (j < n && (s[j] == '\r' || s[j] == '\n')) ++j;
+            return j;
+        }
+    }
+    /* whitespace run [i, e); last_nl = end of its last \r / \n; prev = start of its last character */
+    size_t e = i, last_nl = 0, prev = i, count = 0;
+    while (e < n) {
+        const uint32_t c = cp_at(s, n, e, &a2);
+        if (!is_white_space(c)) break;
+        prev = e; e += a2; ++count;
+        if (c == '\r' || c == '\n') last_nl = e;
+    }
+    if (kind == BLRE_QWEN && last_nl) return last_nl;                     /* \s*[\r\n]+ */
+    if (e == n) return e;                                                 /* \s+(?!\S) at the end of the text */
+    if (count >= 2) return prev;                                          /* \s+(?!\S): all but the last whitespace character */
+    return e > i ? e : i + a0;                                            /* \s+ (or, defensively, one character) */
+}
+
+static void bl_init_tables(glc_tokenizer* tk) {                          /* GPT-2 bytes_to_unicode */
+    int next = 0;
+    for (int b = 0; b < 512; ++b) tk->bl_byte_of[b] = -1;
+    for (int b = 0; b < 256; ++b) {
+        const int keep = (b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174 && b <= 255);
+        tk->bl_cp[b] = (uint16_t)(keep ? b : 256 + next++);
+        tk->bl_byte_of[tk->bl_cp[b]] = (int16_t)b;
+    }
+}
+
+static const bpe_merge* merge_find(const glc_tokenizer* tk, int32_t l, int32_t r) {
+    if (!tk->merge_cap) return NULL;
+    const uint64_t key = ((uint64_t)(uint32_t)l << 32) | (uint32_t)r | (1ull << 63);
+    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tk->merge_cap - 1);
+    while (tk->merges[h].key) { if (tk->merges[h].key == key) return &tk->merges[h]; h = (h + 1) & (tk->merge_cap - 1); }
+    return NULL;
+}
+
+/* One pre-token (already mapped to its printable stand-ins, UTF-8): symbols = characters, then merge the lowest-rank adjacent
+ * pair (leftmost among equals) until none is left — the order the Rust implementation's heap pops them in. */
+static void bpe_word(const glc_tokenizer* tk, const char* w, size_t n, scratch* sc, ivec* out) {
+    if (tk->bpe_ignore_merges) { const int32_t id = vocab_lookup(tk, w, n); if (id >= 0) { iv_push(out, id); return; } }
+    if (sc->seg_cap < n + 1) { free(sc->seg); sc->seg_cap = n + 64; sc->seg = (int32_t*)malloc(sc->seg_cap * sizeof(int32_t)); if (!sc->seg) { sc->seg_cap = 0; return; } }
+    int32_t* sym = sc->seg; size_t ns = 0;
+    for (size_t i = 0; i < n;) {
+        const size_t l = u8_len((unsigned char)w[i]) <= n - i ? u8_len((unsigned char)w[i]) : n - i;
+        const int32_t id = vocab_lookup(tk, w + i, l);
+        if (id >= 0) sym[ns++] = id; else if (tk->unk_id >= 0) sym[ns++] = tk->unk_id;        /* no unk token: the character is dropped */
+        i += l;
+    }
+    while (ns > 1) {
+        int32_t best = INT32_MAX; size_t at = 0; int32_t merged = -1;
+        for (size_t k = 0; k + 1 < ns; ++k) {
+            const bpe_merge* m = merge_find(tk, sym[k], sym[k + 1]);
+            if (m && m->rank < best) { best = m->rank; at = k; merged = m->merged; }
+        }
+        if (merged < 0) break;
+        sym[at] = merged;
+        memmove(sym + at + 1, sym + at + 2, (ns - at - 2) * sizeof(int32_t));
+        --ns;
+    }
+    for (size_t k = 0; k < ns; ++k) iv_push(out, sym[k]);
+}
+
+static void bpe_encode_piece(const glc_tokenizer* tk, const char* s, size_t n, scratch* sc, ivec* out) {
+    const unsigned char* u = (const unsigned char*)s;
+    sbuf* pre = &sc->pre; sbuf* w = &sc->fused;
+    if (tk->pre_bytelevel && tk->bl_prefix_space && n && s[0] != ' ') {   /* ByteLevel add_prefix_space */
+        sb_clear(pre); sb_put(pre, " ", 1); sb_put(pre, s, n);
+        u = (const unsigned char*)pre->s; n = pre->len;
+    }
+    for (size_t i = 0; i < n;) {
+        const size_t e = tk->bl_regex ? bl_next(tk->bl_regex, u, n, i) : n;
+        sb_clear(w);
+        if (tk->pre_bytelevel) {
+            sb_reserve(w, 2 * (e - i) + 2);
+            for (size_t k = i; k < e; ++k) { char t[4]; const size_t l = u8_encode(t, tk->bl_cp[u[k]]); sb_put(w, t, l); }
+        } else sb_put(w, (const char*)u + i, e - i);
+        if (w->len) bpe_word(tk, w->s, w->len, sc, out);
+        i = e > i ? e : i + 1;
+    }
+}
+
 /* ---------------------------------------------------------------- tokenizer.json loading */
 
 static char* dup_n(const char* s, size_t n) {
@@ -777,6 +1010,7 @@ static int load_normalizer(glc_tokenizer* tk, const gj_value* nz, char* err, siz
     if (!st) { snprintf(err, errlen, "out of memory"); return 0; }
     if (!strcmp(type, "Strip")) { st->kind = N_STRIP; st->left = jbool(nz, "strip_left", 1); st->right = jbool(nz, "strip_right", 1); return 1; }
     if (!strcmp(type, "Lowercase")) { st->kind = N_LOWERCASE; return 1; }
+    if (!strcmp(type, "NFC")) { st->kind = N_NFC; return 1; }
     if (!strcmp(type, "Prepend")) {
         size_t l; const char* p = jstr(nz, "prepend", &l);
         if (!p) { snprintf(err, errlen, "normalizer Prepend without text"); return 0; }
@@ -845,15 +1079,107 @@ static int load_pretokenizer(glc_tokenizer* tk, const gj_value* pt, char* err, s
         tk->has_metaspace = 1;
         return 1;
     }
+    if (!strcmp(type, "Split")) {
+        /* the split regex of the byte-level BPE families, recognised by its text (a general regex engine is not part of this library) */
+        static const char QWEN[] = "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+        static const char GPT2[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+        const gj_value* pat = gj_get(pt, "pattern");
+        const char* re = pat ? jstr(pat, "Regex", NULL) : NULL;
+        const char* beh = jstr(pt, "behavior", NULL);
+        if (!re || !beh || strcmp(beh, "Isolated") || jbool(pt, "invert", 0)) { snprintf(err, errlen, "pre_tokenizer Split: only {Regex, Isolated, invert=false} is implemented"); return 0; }
+        if (!strcmp(re, QWEN)) tk->bl_regex = BLRE_QWEN;
+        else if (!strcmp(re, GPT2)) tk->bl_regex = BLRE_GPT2;
+        else { snprintf(err, errlen, "pre_tokenizer Split: unsupported regex (implemented: the GPT-2 and the Qwen2 split patterns)"); return 0; }
+        return 1;
+    }
+    if (!strcmp(type, "ByteLevel")) {
+        tk->pre_bytelevel = 1;
+        tk->bl_prefix_space = jbool(pt, "add_prefix_space", 1);
+        if (jbool(pt, "use_regex", 1)) {
+            if (tk->bl_regex) { snprintf(err, errlen, "pre_tokenizer ByteLevel: use_regex=true after a Split"); return 0; }
+            tk->bl_regex = BLRE_GPT2;
+        }
+        bl_init_tables(tk);
+        return 1;
+    }
     snprintf(err, errlen, "unsupported pre_tokenizer '%s'", type);
     return 0;
 }
 
+/* BPE model: vocab {token: id}, merges ["a b", ...] or [["a", "b"], ...] (rank = position). */
+static int load_model_bpe(glc_tokenizer* tk, const gj_value* m, char* err, size_t errlen) {
+    const gj_value* vocab = gj_get(m, "vocab");
+    const gj_value* merges = gj_get(m, "merges");
+    if (!gj_is(vocab, GJ_OBJ) || !gj_is(merges, GJ_ARR)) { snprintf(err, errlen, "BPE model without vocab / merges"); return 0; }
+    size_t l;
+    const char* csp = jstr(m, "continuing_subword_prefix", &l);
+    if (csp && l) { snprintf(err, errlen, "BPE: continuing_subword_prefix is not implemented"); return 0; }
+    const char* eow = jstr(m, "end_of_word_suffix", &l);
+    if (eow && l) { snprintf(err, errlen, "BPE: end_of_word_suffix is not implemented"); return 0; }
+    if (jbool(m, "byte_fallback", 0)) { snprintf(err, errlen, "BPE: byte_fallback is not implemented"); return 0; }
+    const gj_value* dr = gj_get(m, "dropout");
+    if (gj_is(dr, GJ_NUM) && dr->u.num > 0) { snprintf(err, errlen, "BPE: dropout is not implemented"); return 0; }
+    tk->model_kind = MODEL_BPE;
+    tk->bpe_ignore_merges = jbool(m, "ignore_merges", 0);
+    size_t maxid = 0;
+    for (size_t i = 0; i < vocab->u.obj.n; ++i) {
+        const gj_value* v = vocab->u.obj.vals[i];
+        if (!gj_is(v, GJ_NUM) || v->u.num < 0) { snprintf(err, errlen, "BPE vocab entry %zu has no id", i); return 0; }
+        if ((size_t)v->u.num > maxid) maxid = (size_t)v->u.num;
+    }
+    tk->nvocab = vocab->u.obj.n ? maxid + 1 : 0;
+    tk->tok = (char**)calloc(tk->nvocab ? tk->nvocab : 1, sizeof(char*));
+    tk->toklen = (uint32_t*)calloc(tk->nvocab ? tk->nvocab : 1, sizeof(uint32_t));
+    tk->score = (double*)calloc(tk->nvocab ? tk->nvocab : 1, sizeof(double));
+    if (!tk->tok || !tk->toklen || !tk->score) { snprintf(err, errlen, "out of memory"); return 0; }
+    for (size_t i = 0; i < vocab->u.obj.n; ++i) {
+        const size_t id = (size_t)vocab->u.obj.vals[i]->u.num;
+        const char* k = vocab->u.obj.keys[i];
+        if (tk->tok[id]) { snprintf(err, errlen, "BPE vocab: id %zu twice", id); return 0; }
+        tk->tok[id] = dup_n(k, strlen(k));
+        if (!tk->tok[id]) { snprintf(err, errlen, "out of memory"); return 0; }
+        tk->toklen[id] = (uint32_t)strlen(k);
+    }
+    for (size_t i = 0; i < tk->nvocab; ++i) if (!tk->tok[i]) { tk->tok[i] = dup_n("", 0); if (!tk->tok[i]) { snprintf(err, errlen, "out of memory"); return 0; } }   /* holes in the id space */
+    if (!build_trie(tk)) { snprintf(err, errlen, "out of memory"); return 0; }
+    size_t ul; const char* unk = jstr(m, "unk_token", &ul);
+    tk->unk_id = unk ? vocab_lookup(tk, unk, ul) : -1;
+    tk->merge_cap = 16;
+    while (tk->merge_cap < 2 * merges->u.arr.n + 2) tk->merge_cap *= 2;
+    tk->merges = (bpe_merge*)calloc(tk->merge_cap, sizeof(bpe_merge));
+    sbuf cat = {0, 0, 0};
+    if (!tk->merges) { snprintf(err, errlen, "out of memory"); return 0; }
+    for (size_t i = 0; i < merges->u.arr.n; ++i) {
+        const gj_value* e = merges->u.arr.items[i];
+        const char *a = NULL, *b = NULL; size_t al = 0, bl = 0;
+        if (gj_is(e, GJ_STR)) {
+            const char* sp = (const char*)memchr(e->u.str.s, ' ', e->u.str.len);
+            if (sp) { a = e->u.str.s; al = (size_t)(sp - a); b = sp + 1; bl = e->u.str.len - al - 1; }
+        } else if (gj_is(e, GJ_ARR) && e->u.arr.n == 2 && gj_is(e->u.arr.items[0], GJ_STR) && gj_is(e->u.arr.items[1], GJ_STR)) {
+            a = e->u.arr.items[0]->u.str.s; al = e->u.arr.items[0]->u.str.len; b = e->u.arr.items[1]->u.str.s; bl = e->u.arr.items[1]->u.str.len;
+        }
+        if (!a || !al || !bl) { snprintf(err, errlen, "BPE merge %zu is malformed", i); sb_free(&cat); return 0; }
+        const int32_t ia = vocab_lookup(tk, a, al), ib = vocab_lookup(tk, b, bl);
+        sb_clear(&cat); sb_put(&cat, a, al); sb_put(&cat, b, bl);
+        const int32_t im = vocab_lookup(tk, cat.s, cat.len);
+        if (ia < 0 || ib < 0 || im < 0) { snprintf(err, errlen, "BPE merge %zu names a token outside the vocabulary", i); sb_free(&cat); return 0; }
+        const uint64_t key = ((uint64_t)(uint32_t)ia << 32) | (uint32_t)ib | (1ull << 63);
+        size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tk->merge_cap - 1);
+        while (tk->merges[h].key && tk->merges[h].key != key) h = (h + 1) & (tk->merge_cap - 1);
+        if (!tk->merges[h].key) { tk->merges[h].key = key; tk->merges[h].rank = (int32_t)i; tk->merges[h].merged = im; }   /* first occurrence = lowest rank */
+    }
+    sb_free(&cat);
+    for (int b = 0; b < 256; ++b) tk->byte_ids[b] = -1;
+    tk->id_space = tk->nvocab;
+    return 1;
+}
+
 static int load_model(glc_tokenizer* tk, const gj_value* m, char* err, size_t errlen) {
     const char* type = m ? jstr(m, "type", NULL) : NULL;
+    if (m && type && !strcmp(type, "BPE")) return load_model_bpe(tk, m, err, errlen);
     const gj_value* vocab = gj_get(m, "vocab");
     if (!m || (type && strcmp(type, "Unigram")) || !gj_is(vocab, GJ_ARR)) {
-        snprintf(err, errlen, "unsupported model '%s' (only Unigram is implemented)", type ? type : "?");
+        snprintf(err, errlen, "unsupported model '%s' (implemented: Unigram, byte-level BPE)", type ? type : "?");
         return 0;
     }
     const gj_value* unk = gj_get(m, "unk_id");
@@ -929,6 +1255,13 @@ static int load_postprocessor(glc_tokenizer* tk, const gj_value* pp, char* err, 
         }
         return 1;
     }
+    if (!strcmp(type, "ByteLevel")) return 1;                            /* offsets only: adds no tokens */
+    if (!strcmp(type, "Sequence")) {
+        const gj_value* lst = gj_get(pp, "processors");
+        if (!gj_is(lst, GJ_ARR)) { snprintf(err, errlen, "post_processor Sequence without a list"); return 0; }
+        for (size_t i = 0; i < lst->u.arr.n; ++i) if (!load_postprocessor(tk, lst->u.arr.items[i], err, errlen)) return 0;
+        return 1;
+    }
     if (!strcmp(type, "BertProcessing") || !strcmp(type, "RobertaProcessing")) {
         const gj_value* cls = gj_get(pp, "cls"); const gj_value* sep = gj_get(pp, "sep");
         if (!gj_is(cls, GJ_ARR) || cls->u.arr.n != 2 || !gj_is(sep, GJ_ARR) || sep->u.arr.n != 2) { snprintf(err, errlen, "%s without cls/sep", type); return 0; }
@@ -975,6 +1308,7 @@ static void tokenizer_destroy(glc_tokenizer* tk) {
     free(tk->added);
     for (size_t i = 0; i < tk->ntmpl; ++i) free(tk->tmpl[i].ids);
     free(tk->tmpl);
+    free(tk->merges);
     sb_free(&tk->decoded);
     free(tk);
 }
@@ -989,6 +1323,8 @@ TokenizerHandle tokenizers_new_from_str(const char* json, size_t len) {
     if (ok) { tk->unk_id = -1; ok = load_model(tk, gj_get(root, "model"), err, sizeof err); }
     if (ok) ok = load_normalizer(tk, gj_get(root, "normalizer"), err, sizeof err);
     if (ok) ok = load_pretokenizer(tk, gj_get(root, "pre_tokenizer"), err, sizeof err);
+    if (ok && (tk->pre_bytelevel || tk->bl_regex) && tk->model_kind != MODEL_BPE) { snprintf(err, sizeof err, "Split / ByteLevel pre_tokenizers are implemented for BPE models only"); ok = 0; }
+    if (ok && tk->model_kind == MODEL_BPE && tk->has_metaspace) { snprintf(err, sizeof err, "a BPE model behind a Metaspace pre_tokenizer is not implemented"); ok = 0; }
     if (ok) ok = load_postprocessor(tk, gj_get(root, "post_processor"), err, sizeof err);
     if (ok) ok = load_added(tk, gj_get(root, "added_tokens"), err, sizeof err);
     if (ok) {
@@ -1004,6 +1340,8 @@ TokenizerHandle tokenizers_new_from_str(const char* json, size_t len) {
         const gj_value* dec = gj_get(root, "decoder");
         const char* dt = dec ? jstr(dec, "type", NULL) : NULL;
         tk->dec_metaspace = dt && !strcmp(dt, "Metaspace");
+        tk->dec_bytelevel = dt && !strcmp(dt, "ByteLevel");
+        if (tk->dec_bytelevel && !tk->pre_bytelevel) bl_init_tables(tk);
     }
     gj_free(doc);
     if (!ok) {
@@ -1084,6 +1422,14 @@ void tokenizers_decode(TokenizerHandle handle, const uint32_t* data, size_t len,
                 i += tk->ms_replen;
             } else { sb_put(&tk->decoded, raw.s + i, 1); ++i; }
             first = 0;
+        }
+    } else if (tk->dec_bytelevel && raw.s) {                             /* printable stand-ins back to bytes; anything else passes through */
+        const unsigned char* u = (const unsigned char*)raw.s;
+        for (size_t i = 0; i < raw.len;) {
+            size_t adv; const uint32_t c = u8_decode(u + i, raw.len - i, &adv);
+            if (c < 512 && tk->bl_byte_of[c] >= 0) { const char b = (char)tk->bl_byte_of[c]; sb_put(&tk->decoded, &b, 1); }
+            else sb_put(&tk->decoded, raw.s + i, adv);
+            i += adv;
         }
     } else if (raw.s) sb_put(&tk->decoded, raw.s, raw.len);
     sb_free(&raw);

@@ -13,4 +13,4 @@ gcc -shared -fsanitize=address,undefined -fopenmp -o "$OUT/libgliclass_model.so"
 cd "$REPO"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" GLC_MODEL_SO="$OUT/libgliclass_model.so" \
-    python -m pytest tests/test_host.py tests/test_tokenizer.py -x -q -k "not live"
+    python -m pytest tests/test_host.py tests/test_tokenizer.py tests/test_tokenizer_bpe.py -x -q

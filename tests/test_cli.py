@@ -207,3 +207,37 @@ def test_reference_probe_through_the_launcher(workdir, prompt_first):
     got = {m.group(1): float(m.group(2)) for m in re.finditer(r"  Text_0 Label: (\w+), Score: ([0-9.]+)", r.stdout)}
     assert set(got) == set(want)
     assert max(abs(got[k] - want[k]) for k in want) <= probe["tolerance_atol"] * 0.02       # 2e-5: %.6f printing + fp32, 50x inside the probe's atol
+
+
+@pytest.mark.gpu
+def test_decoder_backbone_text_in_with_the_bpe_tokenizer(workdir):
+    """Config c5's path text-in: the decoder-style backbone behind the launcher with a byte-level BPE tokenizer.json (the tokenizer
+    family of the reference's qwen / llama GLiClass models, Readme.md:91-94; stand-in file tests/golden/bpe_tokenizer.json.gz, ids
+    pinned to the Rust library in tests/test_tokenizer_bpe.py).  Printed scores against the oracle on the same prompts."""
+    import oracle_c
+    from gliclass.c_amd import weights
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.tokenizer import Tokenizer
+    (workdir / "bpe_tok.json").write_bytes(gzip.open(os.path.join(ROOT, "tests", "golden", "bpe_tokenizer.json.gz")).read())
+    cfg = dataclasses.replace(CONFIGS["dec-tiny"], name="dec-tiny-tok", vocab=6002, class_token_index=6000, text_token_index=6001)
+    w = weights.make_weights(cfg, 3)
+    blob = str(workdir / "dec_tiny_tok.glcw")
+    weights.write_blob(blob, cfg, w)
+    data, labels = _write_data(workdir, False, "multi-label", "data_dec.json")
+    env = dict({k: v for k, v in os.environ.items() if not k.startswith("GLICLASS_")}, GLICLASS_THRESHOLD="0.0")      # default mode
+    r = subprocess.run([EXE, data, "true", str(workdir / "bpe_tok.json"), blob], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    tok = Tokenizer((workdir / "bpe_tok.json").read_text())
+    prompts = _prompts(lambda i: labels[i], True)
+    want = []
+    for lo in range(0, len(TEXTS), 8):
+        ids, mask = tok.tokenize_inputs(prompts[lo:lo + 8], 2048)
+        ids, mask = np.array(ids, np.int64), np.array(mask, np.int64)
+        assert ((ids == 6000).sum(1) == [len(labels[i]) for i in range(lo, min(lo + 8, len(TEXTS)))]).all()
+        lg = oracle_c.forward(cfg, w, ids, mask)
+        p = 1.0 / (1.0 + np.exp(-lg.astype(np.float64)))
+        for b in range(ids.shape[0]):
+            want += [p[b, j] for j in range(len(labels[lo + b]))]
+    got = [float(m.group(1)) for m in re.finditer(r"  Text_\d+ Label: (?!\[Unknown\]).+, Score: ([0-9.]+)", r.stdout)]
+    assert len(got) == len(want)
+    assert np.abs(np.array(sorted(got)) - np.array(sorted(want))).max() <= 2e-5

@@ -95,7 +95,7 @@ def test_unsupported_pieces_fail_loudly(tk_json):
     for mutate in (lambda j: j["model"].update(type="BPE"),
                    lambda j: j.update(normalizer={"type": "NFKC"}),
                    lambda j: j.update(pre_tokenizer={"type": "ByteLevel"}),
-                   lambda j: j.update(post_processor={"type": "ByteLevel"}),
+                   lambda j: j["model"].update(type="WordPiece"),
                    lambda j: j["normalizer"]["normalizers"].append({"type": "Replace", "pattern": {"Regex": "a|b"}, "content": "x"})):
         j2 = copy.deepcopy(js)
         mutate(j2)

@@ -56,6 +56,8 @@ struct LayerW {
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; // f32
     void *PK = nullptr, *PQ = nullptr;                                        // T [nh, P, 64]
     void *PKs = nullptr, *PQs = nullptr;                                      // fp32 mode: the same tables as split-f16 units (band kernel, AttnArgs::split)
+    void *W1mx = nullptr, *W2mx = nullptr;                                    // fp32 mode, MX cross terms: fp8 sidecars of W1 / W2 (rows.hip) ...
+    int ws1 = 0, ws2 = 0;                                                     // ... and their per-tensor power-of-two scales
 };
 
 }  // namespace
@@ -69,6 +71,8 @@ struct glc_engine {
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
     bool last_gs = false;           // the last forward ran the group-split pipeline
+    int mx_mask = 0;                // group-split pipeline, cross terms as block-scaled fp8 MFMAs: bit 0 FFN1, bit 1 FFN2 (GLC_MX; gemm256s.hip MX)
+    void *H1mx = nullptr, *FFmx = nullptr;      // MX sidecars of H1 / FF (2 bytes per element)
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
@@ -195,6 +199,10 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
+        if (e->mx_mask) {
+            dfree(e, e->H1mx); e->H1mx = dmalloc(e, (size_t)Mpad * c.hidden * 2); if (!e->H1mx) return false;
+            dfree(e, e->FFmx); e->FFmx = dmalloc(e, (size_t)Mpad * c.inter * 2); if (!e->FFmx) return false;
+        }
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
         e->capM = Mpad;
         e->hidden_cap = 0;   // dump buffer is re-made lazily
@@ -453,14 +461,18 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
         { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
-        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
+        const bool mx1 = gs && (e->mx_mask & 1) && w.W1mx, mx2 = gs && (e->mx_mask & 2) && w.W2mx && I % 64 == 0;
+        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H, mx1 ? e->H1mx : nullptr)
                                     : glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
-        { Prof p(e, PC_FFN1); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
+        if (mx1) { f1.Amx = e->H1mx; f1.Wmx = w.W1mx; f1.mx_ws = w.ws1; }
+        if (mx2) f1.Cmx = e->FFmx;
+        { Prof p(e, PC_FFN1); KCHK(mx1 ? glc_launch_gemm256s_mx(st, EPI_GELU, f1) : gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
+        if (mx2) { f2.Amx = e->FFmx; f2.Wmx = w.W2mx; f2.mx_ws = w.ws2; }
+        { Prof p(e, PC_FFN2); KCHK(mx2 ? glc_launch_gemm256s_mx(st, EPI_RESID, f2) : gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H)
                                     : glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
         if (e->keep_hidden)
@@ -679,6 +691,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
+    if (const char* mv = getenv("GLC_MX")) e->mx_mask = atoi(mv) & 3;       // developer switch (see DESIGN.md "MX cross terms")
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
@@ -752,6 +765,15 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 if (!pm) pm = glc_launch_presplit(e->stream, w.Wo, (size_t)H * H);
                 if (!pm) pm = glc_launch_presplit(e->stream, w.W1, (size_t)I * H);
                 if (!pm) pm = glc_launch_presplit(e->stream, w.W2, (size_t)H * I);
+                if (!pm && e->mx_mask) {         // fp8 sidecars: the tensor's largest weight lands near 224 (e4m3 tops out at 448)
+                    auto wscale = [](const float* x, size_t n) { float m = 0.f; for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(x[i])); return m > 0.f && std::isfinite(m) ? (int)floorf(log2f(224.f / m)) : 0; };
+                    w.ws1 = wscale(t[10], (size_t)I * H); w.ws2 = wscale(t[12], (size_t)H * I);
+                    w.ws1 = w.ws1 > 90 ? 90 : (w.ws1 < -8 ? -8 : w.ws1); w.ws2 = w.ws2 > 90 ? 90 : (w.ws2 < -8 ? -8 : w.ws2);
+                    w.W1mx = dmalloc(e, (size_t)I * H * 2, false); w.W2mx = dmalloc(e, (size_t)H * I * 2, false);
+                    if (!w.W1mx || !w.W2mx) { lok = false; break; }
+                    pm = glc_launch_mx_weight_sidecar(e->stream, w.W1, w.W1mx, (size_t)I * H, w.ws1);
+                    if (!pm) pm = glc_launch_mx_weight_sidecar(e->stream, w.W2, w.W2mx, (size_t)H * I, w.ws2);
+                }
                 if (pm) { set_err(pm); lok = false; break; }
             }
             // position projections (HF:296-302, share_att_key): PQ = query_proj(R)*log2e/sqrt(3d), PK = key_proj(R)

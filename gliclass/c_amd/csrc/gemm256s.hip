@@ -46,9 +46,15 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
 // main loop over K' = 3K/32 steps, where step 3s + r fetches the (lo, hi) / (hi, lo) / (hi, hi) 64-byte parts of group s of the A
 // and W rows.  Epilogues: GELU (exact erf form) / BIAS write C in the GS format; RESID reads the residual in the GS format and
 // writes plain fp32 (the LayerNorm input); QKV writes split-f16 fragment units [8 hi | 8 lo] (glc_common.h f16x8s).
-template <typename T, int EPI, bool VMODE, bool GS = false>
+// MX (with GS): per 64 k the loop runs four sub-steps on the same ring — F0, F1: the hi x hi f16 MFMAs of the two 32-groups (A and W hi parts
+// from the group-split rows); X0, X1: the MX sidecar pieces [32 x8 | 32 lo8] / [32 wlo8 | 32 w8] of the two groups, whose fragments
+// (logical chunk g of the 64-byte piece per lane group g, exactly the f16 read pattern) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 per
+// accumulator: lane groups 0-1 pair x8 with wlo8 (a_hi*b_lo), 2-3 pair lo8 with w8 (a_lo*b_hi); the 2^-SHIFT / 2^-ws factors ride in the
+// per-lane e8m0 scale operands.  96 f16 MFMA steps per 64 k become 64 + 32 scaled ones at 1.65 f16-MFMA times each (measured).
+template <typename T, int EPI, bool VMODE, bool GS = false, bool MX = false>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile0, int ntn) {
     static_assert(!GS || sizeof(T) == 2, "GS operands are f16 halves");
+    static_assert(!MX || GS, "MX sidecars accompany group-split rows");
     typedef typename Frag<T>::type frag_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int wm = wave >> 2, wn = wave & 3;
@@ -77,11 +83,45 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         ga[i] = A + (size_t)(m0 + row) * (GS ? 2 * K : K) + ch * 8;
         gw[i] = W + (size_t)(n0 + row) * (GS ? 2 * K : K) + ch * 8;
     }
+    // MX: per-lane 32-bit byte offsets of fragment row i = 0 (row i = 1 sits a uniform 16 rows further) instead of eight 64-bit
+    // pointers: the loop needs every register it can get
+    unsigned va = 0, vw = 0, vax = 0, vwx = 0;
+    if constexpr (MX) {                     // sidecar rows: 2 bytes per element, 64 bytes per 32-group
+        const int row = wave * 32 + lrow;
+        const int ch = lch ^ swz4(row);
+        va = (unsigned)(((size_t)(m0 + row) * 2 * K + ch * 8) * 2);
+        vw = (unsigned)(((size_t)(n0 + row) * 2 * K + ch * 8) * 2);
+        vax = (unsigned)(((size_t)(m0 + row) * K + ch * 8) * 2);
+        vwx = (unsigned)(((size_t)(n0 + row) * K + ch * 8) * 2);
+    }
     auto stage = [&](int st) {
         unsigned char* sa = smem256 + (st & (NSLOT - 1)) * STAGE + (wave * 32) * ROWB;
         unsigned char* sw = sa + TM * ROWB;
         size_t oa, ow;                          // element offsets of this step's 32 k-values in the A / W rows
-        if constexpr (GS) {
+        if constexpr (MX) {
+            const int q = st & 3, grp = 2 * (st >> 2) + (q & 1);
+            const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A);
+            const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+            if (q >= 2) {                       // X sub-step: both groups' 64-byte sidecar pieces of the W rows (q == 2) / A rows (q == 3);
+                const size_t o = (size_t)(st >> 2) * 128;   // group 0 lands in the slot's first 256 rows, group 1 in the second 256
+                const unsigned char* xb_ = (q == 2 ? reinterpret_cast<const unsigned char*>(p.Wmx) : reinterpret_cast<const unsigned char*>(p.Amx)) + o;
+                const unsigned vx = q == 2 ? vwx : vax;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned char* src = xb_ + (size_t)i * 32 * K + vx;
+                    glds16(src, sa + i * 16 * ROWB);
+                    glds16(src + 64, sw + i * 16 * ROWB);
+                }
+                return;
+            }
+            const size_t o = (size_t)grp * 128;   // F sub-step: the hi halves of the group
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                glds16(Ab + o + (size_t)i * 64 * K + va, sa + i * 16 * ROWB);
+                glds16(Wb + o + (size_t)i * 64 * K + vw, sw + i * 16 * ROWB);
+            }
+            return;
+        } else if constexpr (GS) {
             const int s3 = st / 3, r3 = st - 3 * s3;
             oa = (size_t)s3 * 64 + (r3 == 0 ? 32 : 0);
             ow = (size_t)s3 * 64 + (r3 == 1 ? 32 : 0);
@@ -103,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     // fragment read offsets: row r (+16 i keeps (r>>2)&3), logical chunk g -> physical g ^ swz4(r)
     const int aoff = (wm * 128 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
     const int boff = TM * ROWB + (wn * 64 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
-    const int nk = GS ? 3 * (K / 32) : K / 32;
+    const int nk = MX ? 4 * (K / 64) : GS ? 3 * (K / 32) : K / 32;
     const bool late = wm == 1;            // group 1 runs half a step behind group 0 (one extra barrier up front)
     frag_t af[8], bf[4];
 
@@ -123,6 +163,71 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // P: step 0 is in LDS for everyone
     if (late) __builtin_amdgcn_s_barrier();    // the stagger
+    if constexpr (MX) {
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        typedef __attribute__((ext_vector_type(8))) int i32x8;
+        i32x8 xb[4];
+        // e8m0 scale of this lane's 32-byte block: activation side x8 (groups 0-1) 2^0, lo8 (2-3) 2^-SHIFT; weight side wlo8 2^-(ws+SHIFT), w8 2^-ws
+        const int sc_a = g < 2 ? 127 : 127 - GLC_MX_LO_SHIFT;
+        const int sc_w = g < 2 ? 127 - p.mx_ws - GLC_MX_LO_SHIFT : 127 - p.mx_ws;
+        auto ld8 = [&](const unsigned char* q0) __attribute__((always_inline)) {     // this lane's chunk of both groups' pieces -> one 32-byte operand
+            const i32x4 t0 = *reinterpret_cast<const i32x4*>(q0);
+            const i32x4 t1 = *reinterpret_cast<const i32x4*>(q0 + TM * ROWB);
+            i32x8 r;
+            r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+            return r;
+        };
+        auto substep = [&](const int st, const int q) __attribute__((always_inline)) {
+            // ---- phase A ----
+            if (st + 3 < nk) stage(st + 3);
+            const unsigned char* sb = smem256 + (st & (NSLOT - 1)) * STAGE;
+            i32x8 xa0, xa1;
+            if (q < 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag_t*>(sb + boff + j * 16 * ROWB);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag_t*>(sb + aoff + i * 16 * ROWB);
+            } else if (q == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[j] = ld8(sb + boff - TM * ROWB + j * 16 * ROWB);
+            } else {
+                xa0 = ld8(sb + aoff);
+                xa1 = ld8(sb + aoff + 16 * ROWB);
+            }
+            if (st + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (st + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (q == 2) return;                 // the W pieces sit in registers: nothing to multiply yet, and the slot is free again
+            // ---- phase B ----
+            __builtin_amdgcn_s_setprio(1);
+            if (q < 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { if (!vmode) mma16(bf[j], af[i], acc[i][j]); else mma16(af[i], bf[j], acc[i][j]); }
+                }
+            } else {                            // A pieces just in time: fragment i + 2 is read while i multiplies
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const i32x8 cur = (i & 1) ? xa1 : xa0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // (tied accumulator: with the builtin the allocator rotates the 128 accumulator registers through the loop and spills)
+                        if (!vmode) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[i][j]) : "v"(xb[j]), "v"(cur), "v"(sc_w), "v"(sc_a));
+                        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[i][j]) : "v"(cur), "v"(xb[j]), "v"(sc_a), "v"(sc_w));
+                    }
+                    if (i + 2 < 8) { if (i & 1) xa1 = ld8(sb + aoff + (i + 2) * 16 * ROWB); else xa0 = ld8(sb + aoff + (i + 2) * 16 * ROWB); }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        for (int st = 0; st < nk; st += 4) { substep(st, 0); substep(st + 1, 1); substep(st + 2, 2); substep(st + 3, 3); }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the asm MFMAs are invisible to the hazard recogniser: drain before the epilogue's VALU reads
+    } else
     for (int st = 0; st < nk; ++st) {
         // ---- phase A ----
         if (st + 3 < nk) stage(st + 3);
@@ -316,6 +421,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                         T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * N + (n >> 5) * 64 + (n & 31);
                         *reinterpret_cast<vec8T*>(cp) = o;
                         *reinterpret_cast<vec8T*>(cp + 32) = ol;
+                        if (p.Cmx) mx_store8(reinterpret_cast<unsigned char*>(p.Cmx) + (size_t)m * 2 * N, n, v);     // ... and its MX sidecar
                     }
                 } else {
                     *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n) = o;
@@ -370,11 +476,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     }
 }
 
-template <typename T, int EPI, bool VMODE, bool GS = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+template <typename T, int EPI, bool VMODE, bool GS = false, bool MX = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
     static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
-    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS, MX>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
-    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS, MX>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
     return nullptr;
 }
 template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmArgs& a) {
@@ -426,6 +532,28 @@ const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a) {
         }
     }
     return "gemm256s(gs): bad epilogue";
+}
+
+// ... with the cross terms as block-scaled fp8 MFMAs on the MX sidecars (see the kernel header).  K % 64 == 0.
+const char* glc_launch_gemm256s_mx(hipStream_t st, int epi, const GemmArgs& a) {
+    if (!glc_gemm256s_gs_supported(a, epi) || a.K % 64) return "gemm256s(mx): unsupported shape";
+    if (!a.A || !a.W || !a.Amx || !a.Wmx) return "gemm256s(mx): null operand";
+    if (a.mx_ws < -16 || a.mx_ws > 100) return "gemm256s(mx): weight scale exponent out of range";
+    if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256s(mx): null QKV output"; }
+    else if (!a.C) return "gemm256s(mx): null output";
+    if (epi == EPI_RESID && !a.resid) return "gemm256s(mx): null residual";
+    const int ntn = a.N / TN;
+    switch (epi) {
+        case EPI_BIAS: return launch_e<f16_t, EPI_BIAS, false, true, true>(st, a, 0, ntn);
+        case EPI_GELU: return launch_e<f16_t, EPI_GELU, false, true, true>(st, a, 0, ntn);
+        case EPI_RESID: return launch_e<f16_t, EPI_RESID, false, true, true>(st, a, 0, ntn);
+        case EPI_QKV: {
+            const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
+            const char* m = launch_e<f16_t, EPI_QKV, false, true, true>(st, a, nq, nqk - nq);
+            return m ? m : launch_e<f16_t, EPI_QKV, true, true, true>(st, a, nqk, ntn - nqk);
+        }
+    }
+    return "gemm256s(mx): bad epilogue";
 }
 
 // Host-side shape contract: 16-bit T; Mpad % 256 == 0 (buffers allocated with Mpad rows), N % 256 == 0,

@@ -56,8 +56,6 @@ struct LayerW {
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; // f32
     void *PK = nullptr, *PQ = nullptr;                                        // T [nh, P, 64]
     void *PKs = nullptr, *PQs = nullptr;                                      // fp32 mode: the same tables as split-f16 units (band kernel, AttnArgs::split)
-    void *W1mx = nullptr, *W2mx = nullptr;                                    // fp32 mode, MX cross terms: fp8 sidecars of W1 / W2 (rows.hip) ...
-    int ws1 = 0, ws2 = 0;                                                     // ... and their per-tensor power-of-two scales
 };
 
 }  // namespace
@@ -71,8 +69,6 @@ struct glc_engine {
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
     bool last_gs = false;           // the last forward ran the group-split pipeline
-    int mx_mask = 0;                // group-split pipeline, cross terms as block-scaled fp8 MFMAs: bit 0 FFN1, bit 1 FFN2 (GLC_MX; gemm256s.hip MX)
-    void *H1mx = nullptr, *FFmx = nullptr;      // MX sidecars of H1 / FF (2 bytes per element)
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
@@ -199,10 +195,6 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
-        if (e->mx_mask) {
-            dfree(e, e->H1mx); e->H1mx = dmalloc(e, (size_t)Mpad * c.hidden * 2); if (!e->H1mx) return false;
-            dfree(e, e->FFmx); e->FFmx = dmalloc(e, (size_t)Mpad * c.inter * 2); if (!e->FFmx) return false;
-        }
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
         e->capM = Mpad;
         e->hidden_cap = 0;   // dump buffer is re-made lazily
@@ -430,8 +422,8 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     };
     const bool prune = e->prune_last && !e->keep_hidden && c.pooling == GLC_POOL_FIRST;
     // Group-split pipeline of the fp32 mode: the activations that feed GEMMs (X, H1, FF, CTX) are kept as [32 hi | 32 lo] f16 groups
-    // (same bytes as fp32), written by their producers, so that every projection runs on the 256-tile LDS-DMA kernel as a K' = 3K
-    // loop (gemm256s.hip, GS).  Needs the split-f16 weights and attention, the pruned last layer (its compact rows go back to plain
+    // (same bytes as fp32), written by their producers, so that every projection runs on the 256-tile LDS-DMA kernel with three
+    // f16 MFMAs per product (gemm256s.hip, GS).  Needs the split-f16 weights and attention, the pruned last layer (its compact rows go back to plain
     // fp32 and the small-M kernels) and shapes the 256-tile kernel takes; small forwards stay on the 128-tile split-K kernels.
     bool gs = false;
     if (dt == GLC_F32 && e->gs_mode > 0 && e->w_presplit && asplit && impl == 3 && prune && H % 256 == 0 && I % 256 == 0) {
@@ -461,18 +453,14 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
         { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
-        const bool mx1 = gs && (e->mx_mask & 1) && w.W1mx, mx2 = gs && (e->mx_mask & 2) && w.W2mx && I % 64 == 0;
-        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H, mx1 ? e->H1mx : nullptr)
+        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
                                     : glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
-        if (mx1) { f1.Amx = e->H1mx; f1.Wmx = w.W1mx; f1.mx_ws = w.ws1; }
-        if (mx2) f1.Cmx = e->FFmx;
-        { Prof p(e, PC_FFN1); KCHK(mx1 ? glc_launch_gemm256s_mx(st, EPI_GELU, f1) : gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
+        { Prof p(e, PC_FFN1); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
-        if (mx2) { f2.Amx = e->FFmx; f2.Wmx = w.W2mx; f2.mx_ws = w.ws2; }
-        { Prof p(e, PC_FFN2); KCHK(mx2 ? glc_launch_gemm256s_mx(st, EPI_RESID, f2) : gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
+        { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H)
                                     : glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
         if (e->keep_hidden)
@@ -691,7 +679,6 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
-    if (const char* mv = getenv("GLC_MX")) e->mx_mask = atoi(mv) & 3;       // developer switch (see DESIGN.md "MX cross terms")
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
@@ -765,15 +752,6 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 if (!pm) pm = glc_launch_presplit(e->stream, w.Wo, (size_t)H * H);
                 if (!pm) pm = glc_launch_presplit(e->stream, w.W1, (size_t)I * H);
                 if (!pm) pm = glc_launch_presplit(e->stream, w.W2, (size_t)H * I);
-                if (!pm && e->mx_mask) {         // fp8 sidecars: the tensor's largest weight lands near 224 (e4m3 tops out at 448)
-                    auto wscale = [](const float* x, size_t n) { float m = 0.f; for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(x[i])); return m > 0.f && std::isfinite(m) ? (int)floorf(log2f(224.f / m)) : 0; };
-                    w.ws1 = wscale(t[10], (size_t)I * H); w.ws2 = wscale(t[12], (size_t)H * I);
-                    w.ws1 = w.ws1 > 90 ? 90 : (w.ws1 < -8 ? -8 : w.ws1); w.ws2 = w.ws2 > 90 ? 90 : (w.ws2 < -8 ? -8 : w.ws2);
-                    w.W1mx = dmalloc(e, (size_t)I * H * 2, false); w.W2mx = dmalloc(e, (size_t)H * I * 2, false);
-                    if (!w.W1mx || !w.W2mx) { lok = false; break; }
-                    pm = glc_launch_mx_weight_sidecar(e->stream, w.W1, w.W1mx, (size_t)I * H, w.ws1);
-                    if (!pm) pm = glc_launch_mx_weight_sidecar(e->stream, w.W2, w.W2mx, (size_t)H * I, w.ws2);
-                }
                 if (pm) { set_err(pm); lok = false; break; }
             }
             // position projections (HF:296-302, share_att_key): PQ = query_proj(R)*log2e/sqrt(3d), PK = key_proj(R)
@@ -1082,11 +1060,13 @@ int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems)
 /* Developer microbenchmark: time `iters` launches of one GEMM shape on random 16-bit data (HIP events).
  * which: 0 = auto (256-tile when possible), 1 = force the 128x128 kernel.  Returns ms per launch or <0. */
 float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which) {
-    if (!e || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || e->dtype == GLC_F32 || epi < EPI_BIAS || epi > EPI_RESID) { set_err("gemm_bench: bad args"); return -1.f; }
+    // which == 6: the group-split fp32-mode kernel (rows of [32 hi | 32 lo] f16 groups, 4 bytes per element; any engine dtype)
+    const bool gsb = which == 6;
+    if (!e || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (e->dtype == GLC_F32 && !gsb) || epi < EPI_BIAS || epi > EPI_RESID) { set_err("gemm_bench: bad args"); return -1.f; }
     if (M % 256 || N % 256 || K % 64) { set_err("gemm_bench: M,N %256, K %64 required"); return -1.f; }
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHK(hipSetDevice(e->device), -1.f);
-    const size_t es = 2;
+    const size_t es = gsb ? 4 : 2;
     void *A = nullptr, *W = nullptr, *C = nullptr, *R = nullptr; float *bias = nullptr, *tmp = nullptr;
     const size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
     const size_t nmax = nA > nW ? (nA > nC ? nA : nC) : (nW > nC ? nW : nC);
@@ -1098,12 +1078,17 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         unsigned s = 12345u;
         for (size_t i = 0; i < nmax; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((float)(s >> 8) / 8388608.f - 1.f) * 0.5f; }
         if (hipMemcpy(tmp, h.data(), nmax * sizeof(float), hipMemcpyHostToDevice)) { set_err("gemm_bench: copy failed"); break; }
+        if (gsb) {      // fp32 values, split in place into the group-split image
+            if (hipMemcpyAsync(A, tmp, nA * 4, hipMemcpyDeviceToDevice, e->stream) || hipMemcpyAsync(W, tmp, nW * 4, hipMemcpyDeviceToDevice, e->stream) ||
+                hipMemcpyAsync(R, tmp, nC * 4, hipMemcpyDeviceToDevice, e->stream) || glc_launch_presplit(e->stream, A, nA) ||
+                glc_launch_presplit(e->stream, W, nW) || glc_launch_presplit(e->stream, R, nC)) { set_err("gemm_bench: split failed"); break; }
+        } else
         if (glc_launch_convert(e->stream, e->dtype, tmp, A, nA) || glc_launch_convert(e->stream, e->dtype, tmp, W, nW) ||
             glc_launch_convert(e->stream, e->dtype, tmp, R, nC)) { set_err("gemm_bench: convert failed"); break; }
         if (hipMemcpyAsync(bias, tmp, N * sizeof(float), hipMemcpyDeviceToDevice, e->stream)) break;
         GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K;
         const char* m = nullptr;
-        auto launch = [&]() -> const char* { return which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : which == 5 ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
+        auto launch = [&]() -> const char* { return gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : which == 5 ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
         if (m) { set_err(m); break; }
         if (hipEventRecord(e->t0, e->stream)) break;

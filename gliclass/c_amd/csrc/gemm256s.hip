@@ -42,19 +42,13 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
 }
 
 // GS (T = f16_t only): the operands of the fp32 mode.  A and W hold group-split rows (glc_kernels.h: every 32 fp32 values stored as
-// [32 hi halves | 32 lo halves], 128 bytes), and a product is the three f16 MFMAs a_lo*w_hi + a_hi*w_lo + a_hi*w_hi: the SAME
-// main loop over K' = 3K/32 steps, where step 3s + r fetches the (lo, hi) / (hi, lo) / (hi, hi) 64-byte parts of group s of the A
-// and W rows.  Epilogues: GELU (exact erf form) / BIAS write C in the GS format; RESID reads the residual in the GS format and
+// [32 hi halves | 32 lo halves], 128 bytes), and a product is the three f16 MFMAs a_lo*w_hi + a_hi*w_lo + a_hi*w_hi: the same
+// ring and phases over 2K/32 stages, where stage 2s fetches the (hi, lo) and stage 2s + 1 the (lo, hi) 64-byte parts of group s of
+// the A and W rows (see the main loop: every part is fetched once, the a_hi fragments wait in registers).  Epilogues: GELU (exact erf form) / BIAS write C in the GS format; RESID reads the residual in the GS format and
 // writes plain fp32 (the LayerNorm input); QKV writes split-f16 fragment units [8 hi | 8 lo] (glc_common.h f16x8s).
-// MX (with GS): per 64 k the loop runs four sub-steps on the same ring — F0, F1: the hi x hi f16 MFMAs of the two 32-groups (A and W hi parts
-// from the group-split rows); X0, X1: the MX sidecar pieces [32 x8 | 32 lo8] / [32 wlo8 | 32 w8] of the two groups, whose fragments
-// (logical chunk g of the 64-byte piece per lane group g, exactly the f16 read pattern) feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 per
-// accumulator: lane groups 0-1 pair x8 with wlo8 (a_hi*b_lo), 2-3 pair lo8 with w8 (a_lo*b_hi); the 2^-SHIFT / 2^-ws factors ride in the
-// per-lane e8m0 scale operands.  96 f16 MFMA steps per 64 k become 64 + 32 scaled ones at 1.65 f16-MFMA times each (measured).
-template <typename T, int EPI, bool VMODE, bool GS = false, bool MX = false>
+template <typename T, int EPI, bool VMODE, bool GS = false>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile0, int ntn) {
     static_assert(!GS || sizeof(T) == 2, "GS operands are f16 halves");
-    static_assert(!MX || GS, "MX sidecars accompany group-split rows");
     typedef typename Frag<T>::type frag_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int wm = wave >> 2, wn = wave & 3;
@@ -83,48 +77,14 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         ga[i] = A + (size_t)(m0 + row) * (GS ? 2 * K : K) + ch * 8;
         gw[i] = W + (size_t)(n0 + row) * (GS ? 2 * K : K) + ch * 8;
     }
-    // MX: per-lane 32-bit byte offsets of fragment row i = 0 (row i = 1 sits a uniform 16 rows further) instead of eight 64-bit
-    // pointers: the loop needs every register it can get
-    unsigned va = 0, vw = 0, vax = 0, vwx = 0;
-    if constexpr (MX) {                     // sidecar rows: 2 bytes per element, 64 bytes per 32-group
-        const int row = wave * 32 + lrow;
-        const int ch = lch ^ swz4(row);
-        va = (unsigned)(((size_t)(m0 + row) * 2 * K + ch * 8) * 2);
-        vw = (unsigned)(((size_t)(n0 + row) * 2 * K + ch * 8) * 2);
-        vax = (unsigned)(((size_t)(m0 + row) * K + ch * 8) * 2);
-        vwx = (unsigned)(((size_t)(n0 + row) * K + ch * 8) * 2);
-    }
     auto stage = [&](int st) {
         unsigned char* sa = smem256 + (st & (NSLOT - 1)) * STAGE + (wave * 32) * ROWB;
         unsigned char* sw = sa + TM * ROWB;
         size_t oa, ow;                          // element offsets of this step's 32 k-values in the A / W rows
-        if constexpr (MX) {
-            const int q = st & 3, grp = 2 * (st >> 2) + (q & 1);
-            const unsigned char* Ab = reinterpret_cast<const unsigned char*>(p.A);
-            const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
-            if (q >= 2) {                       // X sub-step: both groups' 64-byte sidecar pieces of the W rows (q == 2) / A rows (q == 3);
-                const size_t o = (size_t)(st >> 2) * 128;   // group 0 lands in the slot's first 256 rows, group 1 in the second 256
-                const unsigned char* xb_ = (q == 2 ? reinterpret_cast<const unsigned char*>(p.Wmx) : reinterpret_cast<const unsigned char*>(p.Amx)) + o;
-                const unsigned vx = q == 2 ? vwx : vax;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const unsigned char* src = xb_ + (size_t)i * 32 * K + vx;
-                    glds16(src, sa + i * 16 * ROWB);
-                    glds16(src + 64, sw + i * 16 * ROWB);
-                }
-                return;
-            }
-            const size_t o = (size_t)grp * 128;   // F sub-step: the hi halves of the group
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                glds16(Ab + o + (size_t)i * 64 * K + va, sa + i * 16 * ROWB);
-                glds16(Wb + o + (size_t)i * 64 * K + vw, sw + i * 16 * ROWB);
-            }
-            return;
-        } else if constexpr (GS) {
-            const int s3 = st / 3, r3 = st - 3 * s3;
-            oa = (size_t)s3 * 64 + (r3 == 0 ? 32 : 0);
-            ow = (size_t)s3 * 64 + (r3 == 1 ? 32 : 0);
+        if constexpr (GS) {
+            // two stages per 32-group: (a_hi, w_lo), then (a_lo, w_hi); the a_hi fragments stay in registers for the second one
+            oa = (size_t)(st >> 1) * 64 + ((st & 1) ? 32 : 0);
+            ow = (size_t)(st >> 1) * 64 + ((st & 1) ? 0 : 32);
         } else oa = ow = (size_t)st * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -143,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     // fragment read offsets: row r (+16 i keeps (r>>2)&3), logical chunk g -> physical g ^ swz4(r)
     const int aoff = (wm * 128 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
     const int boff = TM * ROWB + (wn * 64 + r16) * ROWB + ((g ^ swz4(r16)) * 16);
-    const int nk = MX ? 4 * (K / 64) : GS ? 3 * (K / 32) : K / 32;
+    const int nk = GS ? 2 * (K / 32) : K / 32;
     const bool late = wm == 1;            // group 1 runs half a step behind group 0 (one extra barrier up front)
     frag_t af[8], bf[4];
 
@@ -163,70 +123,50 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // P: step 0 is in LDS for everyone
     if (late) __builtin_amdgcn_s_barrier();    // the stagger
-    if constexpr (MX) {
-        typedef __attribute__((ext_vector_type(4))) int i32x4;
-        typedef __attribute__((ext_vector_type(8))) int i32x8;
-        i32x8 xb[4];
-        // e8m0 scale of this lane's 32-byte block: activation side x8 (groups 0-1) 2^0, lo8 (2-3) 2^-SHIFT; weight side wlo8 2^-(ws+SHIFT), w8 2^-ws
-        const int sc_a = g < 2 ? 127 : 127 - GLC_MX_LO_SHIFT;
-        const int sc_w = g < 2 ? 127 - p.mx_ws - GLC_MX_LO_SHIFT : 127 - p.mx_ws;
-        auto ld8 = [&](const unsigned char* q0) __attribute__((always_inline)) {     // this lane's chunk of both groups' pieces -> one 32-byte operand
-            const i32x4 t0 = *reinterpret_cast<const i32x4*>(q0);
-            const i32x4 t1 = *reinterpret_cast<const i32x4*>(q0 + TM * ROWB);
-            i32x8 r;
-            r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
-            return r;
-        };
-        auto substep = [&](const int st, const int q) __attribute__((always_inline)) {
+    if constexpr (GS) {
+        // Group-split rows, two ring stages per 32-group instead of one per product: stage 2s brings (a_hi, w_lo) -> 32 MFMAs a_hi*w_lo,
+        // stage 2s+1 brings (a_lo, w_hi) -> 64 MFMAs a_lo*w_hi + a_hi*w_hi with the a_hi fragments kept in 32 registers: a third less
+        // LDS-DMA traffic and a third fewer load phases / barriers for the same 96 MFMAs (measured -10 % per GEMM at c3).
+        frag_t ah[8];
+        auto substep = [&](const int st, const int odd) __attribute__((always_inline)) {
             // ---- phase A ----
             if (st + 3 < nk) stage(st + 3);
-            const unsigned char* sb = smem256 + (st & (NSLOT - 1)) * STAGE;
-            i32x8 xa0, xa1;
-            if (q < 2) {
+            {
+                const unsigned char* sb = smem256 + (st & (NSLOT - 1)) * STAGE;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const frag_t*>(sb + boff + j * 16 * ROWB);
+                if (!odd) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag_t*>(sb + aoff + i * 16 * ROWB);
-            } else if (q == 2) {
+                    for (int i = 0; i < 8; ++i) ah[i] = *reinterpret_cast<const frag_t*>(sb + aoff + i * 16 * ROWB);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xb[j] = ld8(sb + boff - TM * ROWB + j * 16 * ROWB);
-            } else {
-                xa0 = ld8(sb + aoff);
-                xa1 = ld8(sb + aoff + 16 * ROWB);
+                    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag_t*>(sb + aoff + i * 16 * ROWB);
+                }
             }
             if (st + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             else if (st + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            if (q == 2) return;                 // the W pieces sit in registers: nothing to multiply yet, and the slot is free again
             // ---- phase B ----
             __builtin_amdgcn_s_setprio(1);
-            if (q < 2) {
+            if (odd) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { if (!vmode) mma16(bf[j], af[i], acc[i][j]); else mma16(af[i], bf[j], acc[i][j]); }
                 }
-            } else {                            // A pieces just in time: fragment i + 2 is read while i multiplies
+            }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const i32x8 cur = (i & 1) ? xa1 : xa0;
+            for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // (tied accumulator: with the builtin the allocator rotates the 128 accumulator registers through the loop and spills)
-                        if (!vmode) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[i][j]) : "v"(xb[j]), "v"(cur), "v"(sc_w), "v"(sc_a));
-                        else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc[i][j]) : "v"(cur), "v"(xb[j]), "v"(sc_a), "v"(sc_w));
-                    }
-                    if (i + 2 < 8) { if (i & 1) xa1 = ld8(sb + aoff + (i + 2) * 16 * ROWB); else xa0 = ld8(sb + aoff + (i + 2) * 16 * ROWB); }
-                }
+                for (int j = 0; j < 4; ++j) { if (!vmode) mma16(bf[j], ah[i], acc[i][j]); else mma16(ah[i], bf[j], acc[i][j]); }
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         };
-        for (int st = 0; st < nk; st += 4) { substep(st, 0); substep(st + 1, 1); substep(st + 2, 2); substep(st + 3, 3); }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the asm MFMAs are invisible to the hazard recogniser: drain before the epilogue's VALU reads
+        for (int st = 0; st < nk; st += 2) { substep(st, 0); substep(st + 1, 1); }
     } else
     for (int st = 0; st < nk; ++st) {
         // ---- phase A ----
@@ -335,15 +275,20 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
                 if constexpr (GS) {
-                    const int n = n0 + wn * 64 + g8 * 8;
-                    if (p.gs_resid_plain) {      // plain fp32 residual row: its 8 floats ride in the two 16-byte registers
-                        const float* rp = reinterpret_cast<const float*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * N + n;
+                    // "wide" lane map of the fp32-row epilogue: a lane owns columns [4 g8, +4) and [32 + 4 g8, +4) of the wave's 64, so that
+                    // each store / load instruction covers whole 128-byte row segments (8 floats per lane left 16-byte holes: +8 % per GEMM)
+                    const int na = n0 + wn * 64 + g8 * 4;
+                    typedef __attribute__((ext_vector_type(4))) T vec4T;
+                    if (p.gs_resid_plain) {      // plain fp32 residual row: its 2 x 4 floats ride in the two 16-byte registers
+                        const float* rp = reinterpret_cast<const float*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * N + na;
                         r[k] = __builtin_bit_cast(vec8T, *reinterpret_cast<const f32x4*>(rp));
-                        rl[k] = __builtin_bit_cast(vec8T, *reinterpret_cast<const f32x4*>(rp + 4));
-                    } else {
-                        const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
-                        r[k] = *reinterpret_cast<const vec8T*>(rp);
-                        rl[k] = *reinterpret_cast<const vec8T*>(rp + 32);
+                        rl[k] = __builtin_bit_cast(vec8T, *reinterpret_cast<const f32x4*>(rp + 32));
+                    } else {                     // group-split residual row: r = [4 hi of a | 4 hi of b], rl = the lo halves
+                        const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (na >> 5) * 64 + (na & 31);
+                        const vec4T ha = *reinterpret_cast<const vec4T*>(rp), la = *reinterpret_cast<const vec4T*>(rp + 32);
+                        const vec4T hb = *reinterpret_cast<const vec4T*>(rp + 64), lb = *reinterpret_cast<const vec4T*>(rp + 96);
+                        r[k] = (vec8T){ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+                        rl[k] = (vec8T){la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
                     }
                 } else {
                     r[k] = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) +
@@ -381,11 +326,12 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8 + 4);
+                constexpr bool wide = GS && EPI == EPI_RESID;      // fp32 row output: see load_resid
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 68 + (wide ? g8 * 4 : g8 * 8));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 68 + (wide ? 32 + g8 * 4 : g8 * 8 + 4));
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const int m = m0 + wm * 128 + c * 32 + row;
-                const int n = n0 + wn * 64 + g8 * 8;
+                const int n = n0 + wn * 64 + (wide ? g8 * 4 : g8 * 8);
                 if (EPI == EPI_RESID) {
                     if (GS && p.gs_resid_plain) {
                         const f32x4 ra = __builtin_bit_cast(f32x4, rcur[k]), rb = __builtin_bit_cast(f32x4, rcur_lo[GS ? k : 0]);
@@ -416,12 +362,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                     if (EPI == EPI_RESID || p.gs_c_plain) {         // plain fp32 row (LayerNorm input; decoder: QKV / gate|up rows)
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                        *reinterpret_cast<f32x4*>(cp + (wide ? 32 : 4)) = (f32x4){v[4], v[5], v[6], v[7]};
                     } else {                        // GS row
                         T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * N + (n >> 5) * 64 + (n & 31);
                         *reinterpret_cast<vec8T*>(cp) = o;
                         *reinterpret_cast<vec8T*>(cp + 32) = ol;
-                        if (p.Cmx) mx_store8(reinterpret_cast<unsigned char*>(p.Cmx) + (size_t)m * 2 * N, n, v);     // ... and its MX sidecar
                     }
                 } else {
                     *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n) = o;
@@ -476,11 +421,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     }
 }
 
-template <typename T, int EPI, bool VMODE, bool GS = false, bool MX = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+template <typename T, int EPI, bool VMODE, bool GS = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
     static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
-    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS, MX>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
-    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS, MX>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
     return nullptr;
 }
 template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmArgs& a) {
@@ -512,7 +457,7 @@ bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi) {
     return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_SWIGLU;
 }
 
-// fp32 mode on group-split operands (see the kernel header): T = f16 halves, K' = 3K/32 steps.
+// fp32 mode on group-split operands (see the kernel header): T = f16 halves, 2K/32 ring stages for 3K/32 MFMA steps.
 const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a) {
     if (!glc_gemm256s_gs_supported(a, epi)) return "gemm256s(gs): unsupported shape";
     if (!a.A || !a.W) return "gemm256s(gs): null operand";
@@ -532,28 +477,6 @@ const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a) {
         }
     }
     return "gemm256s(gs): bad epilogue";
-}
-
-// ... with the cross terms as block-scaled fp8 MFMAs on the MX sidecars (see the kernel header).  K % 64 == 0.
-const char* glc_launch_gemm256s_mx(hipStream_t st, int epi, const GemmArgs& a) {
-    if (!glc_gemm256s_gs_supported(a, epi) || a.K % 64) return "gemm256s(mx): unsupported shape";
-    if (!a.A || !a.W || !a.Amx || !a.Wmx) return "gemm256s(mx): null operand";
-    if (a.mx_ws < -16 || a.mx_ws > 100) return "gemm256s(mx): weight scale exponent out of range";
-    if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256s(mx): null QKV output"; }
-    else if (!a.C) return "gemm256s(mx): null output";
-    if (epi == EPI_RESID && !a.resid) return "gemm256s(mx): null residual";
-    const int ntn = a.N / TN;
-    switch (epi) {
-        case EPI_BIAS: return launch_e<f16_t, EPI_BIAS, false, true, true>(st, a, 0, ntn);
-        case EPI_GELU: return launch_e<f16_t, EPI_GELU, false, true, true>(st, a, 0, ntn);
-        case EPI_RESID: return launch_e<f16_t, EPI_RESID, false, true, true>(st, a, 0, ntn);
-        case EPI_QKV: {
-            const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
-            const char* m = launch_e<f16_t, EPI_QKV, false, true, true>(st, a, nq, nqk - nq);
-            return m ? m : launch_e<f16_t, EPI_QKV, true, true, true>(st, a, nqk, ntn - nqk);
-        }
-    }
-    return "gemm256s(mx): bad epilogue";
 }
 
 // Host-side shape contract: 16-bit T; Mpad % 256 == 0 (buffers allocated with Mpad rows), N % 256 == 0,

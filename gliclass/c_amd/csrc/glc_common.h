@@ -155,26 +155,6 @@ __device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]
     for (int e = 0; e < 8; ++e) v[e] = (float)hi[e] + (float)lo[e];
 }
 
-// "MX sidecar" of a group-split row (the fp32 mode's low-precision correction terms, gemm256s.hip MX): per 32 elements 64 bytes
-// [32 x fp8(x) | 32 x fp8((x - f16(x)) * 2^GLC_MX_LO_SHIFT)] (e4m3, saturating).  The cross terms a_hi*b_lo + a_lo*b_hi of a split-f16
-// product then run as ONE block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, K' = 2 x 64) instead of two f16 MFMA steps per 32 k;
-// the 2^-SHIFT comes back through the instruction's e8m0 scale operand.  SHIFT = 10 keeps the scaled residual of any |x| < 1024 in range.
-#define GLC_MX_LO_SHIFT 10
-__device__ __forceinline__ uint32_t glc_fp8x4(float a, float b, float c, float d) {
-    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f); c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (uint32_t)w;
-}
-__device__ __forceinline__ void mx_store8(unsigned char* row, int e0, const float (&v)[8]) {      // e0 % 8 == 0; row = sidecar row (2 bytes per element)
-    float l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) l[e] = (v[e] - (float)(f16_t)v[e]) * (float)(1 << GLC_MX_LO_SHIFT);
-    unsigned char* p = row + (e0 >> 5) * 64 + (e0 & 31);
-    *reinterpret_cast<u32x2*>(p) = (u32x2){glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
-    *reinterpret_cast<u32x2*>(p + 32) = (u32x2){glc_fp8x4(l[0], l[1], l[2], l[3]), glc_fp8x4(l[4], l[5], l[6], l[7])};
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -32,9 +32,6 @@ struct GemmArgs {
     // gemm256s on group-split operands (glc_launch_gemm256s_gs): EPI_BIAS / EPI_GELU write C as plain fp32 rows instead of GS rows;
     // EPI_RESID reads its residual as plain fp32 rows instead of GS rows (decoder backbone: the residual stream itself)
     int gs_c_plain = 0, gs_resid_plain = 0;
-    // ... with low-precision correction terms (glc_launch_gemm256s_mx): MX sidecars of A [Mpad, K] and W [N, K] (2 bytes per element,
-    // glc_common.h), the weight scale exponent (w8 = fp8(w * 2^mx_ws)), and, for EPI_GELU / EPI_BIAS, the sidecar of C to write (or null)
-    const void* Amx = nullptr; const void* Wmx = nullptr; void* Cmx = nullptr; int mx_ws = 0;
 };
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);
@@ -58,19 +55,15 @@ const char* glc_launch_layernorm(hipStream_t st, int dtype, const void* X, void*
 
 // ---- group-split ("GS") activations of the fp32 mode (rows.hip): a row of K fp32 values kept in the same 4 K bytes as K / 32 groups
 // of [32 hi halves | 32 lo halves] (x = hi + lo), the operand image of the split-f16 GEMMs ----
-const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H, void* Ymx = nullptr);   // Ymx: also write the MX sidecar
+const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H);
 const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_t* mask, const float* table, const float* gamma,
                                 const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id);
 const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* cls_pos, int c_cap, float* Xs, int* sel_b, int* sel_q,
                                       unsigned char* tile_flag, int B, int Sp, int H, int C);
 // 256x256 LDS-DMA GEMM on GS operands (gemm256s.hip): A [Mpad, K] and W [N, K] in the GS format; three f16 MFMAs per product
-// (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi), i.e. a K' = 3K loop of the 16-bit kernel.  EPI_GELU / EPI_BIAS: C in the GS format;
+// (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) on the 16-bit kernel's ring, every 64-byte part fetched once.  EPI_GELU / EPI_BIAS: C in the GS format;
 // EPI_RESID: resid in the GS format, C plain fp32 (the LayerNorm input); EPI_QKV: Q / K / V^T as split-f16 units (qkv_split).
 bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi);
-// the same GEMM with the two cross terms of every split-f16 product as one block-scaled fp8 MFMA on the MX sidecars (K % 64 == 0)
-const char* glc_launch_gemm256s_mx(hipStream_t st, int epi, const GemmArgs& a);
-// MX sidecar of group-split WEIGHT rows [n, K] (in: presplit rows; out: per 32 elements [32 x fp8(lo * 2^(ws+SHIFT)) | 32 x fp8(w * 2^ws)])
-const char* glc_launch_mx_weight_sidecar(hipStream_t st, const void* w_gs, void* w_mx, size_t n_elems, int ws);
 const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a);
 
 // Embedding gather + LayerNorm + mask (modeling_deberta_v2.py:533,550,552-559) on the padded

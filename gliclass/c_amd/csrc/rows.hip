@@ -62,7 +62,7 @@ __device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restri
 // LayerNorm of one fp32 row by one wave, output in the GS format (8 elements per lane and chunk)
 template <bool MASKED>
 __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_t* __restrict__ y, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float eps, int H, float mk, int lane, unsigned char* ymx = nullptr) {
+                                               const float* __restrict__ beta, float eps, int H, float mk, int lane) {
     const int nch = H / 8;
     float v[MAXC][8];
     float s = 0.f;
@@ -97,28 +97,14 @@ __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_
                 o[e] = r;
             }
             gs_store8(y, ch * 8, o);
-            if (ymx) mx_store8(ymx, ch * 8, o);
         }
     }
 }
 __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, int M, int H, unsigned char* __restrict__ Ymx) {
+                                                           const float* __restrict__ beta, float eps, int M, int H) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63, Ymx ? Ymx + (size_t)row * 2 * H : nullptr);
-}
-// MX sidecar of presplit (group-split) weight rows: per 32 elements [32 x fp8(lo * 2^(ws + SHIFT)) | 32 x fp8((hi + lo) * 2^ws)]
-__global__ __launch_bounds__(256) void mx_weight_sidecar_kernel(const f16_t* __restrict__ w, unsigned char* __restrict__ out, size_t ngroups, float s_w, float s_lo) {
-    const size_t gi = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2);      // 4 lanes per group of 32 elements, 8 elements each
-    if (gi >= ngroups) return;
-    const int o = (threadIdx.x & 3) * 8;
-    const gs_h8 hi = *reinterpret_cast<const gs_h8*>(w + gi * 64 + o), lo = *reinterpret_cast<const gs_h8*>(w + gi * 64 + 32 + o);
-    float a[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { a[e] = ((float)hi[e] + (float)lo[e]) * s_w; l[e] = (float)lo[e] * s_lo; }
-    unsigned char* p = out + gi * 64 + o;
-    *reinterpret_cast<u32x2*>(p) = (u32x2){glc_fp8x4(l[0], l[1], l[2], l[3]), glc_fp8x4(l[4], l[5], l[6], l[7])};
-    *reinterpret_cast<u32x2*>(p + 32) = (u32x2){glc_fp8x4(a[0], a[1], a[2], a[3]), glc_fp8x4(a[4], a[5], a[6], a[7])};
+    ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
 }
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,
@@ -388,18 +374,10 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
     return nullptr;
 }
 
-const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H, void* Ymx) {
+const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H) {
     if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm_gs: bad args";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "layernorm_gs: unsupported hidden size";
-    hipLaunchKernelGGL(layernorm_gs_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, (unsigned char*)Ymx);
-    return nullptr;
-}
-
-const char* glc_launch_mx_weight_sidecar(hipStream_t st, const void* w_gs, void* w_mx, size_t n_elems, int ws) {
-    if (!w_gs || !w_mx || n_elems % 32 || ws < -100 || ws > 100) return "mx_weight_sidecar: bad args";
-    const size_t groups = n_elems / 32;
-    if (groups) hipLaunchKernelGGL(mx_weight_sidecar_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(256), 0, st, (const f16_t*)w_gs,
-                                   (unsigned char*)w_mx, groups, ldexpf(1.0f, ws), ldexpf(1.0f, ws + GLC_MX_LO_SHIFT));
+    hipLaunchKernelGGL(layernorm_gs_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
     return nullptr;
 }
 

@@ -16,7 +16,8 @@
 //   * Saturated key tiles (every q - k beyond the bucket clamp for ALL waves of the workgroup) run as before, per wave, on the shared
 //     K / V^T tiles.
 // Synchronisation per band tile: barrier X (every wave has finished gathering the previous tile's p2c image) -> p2c stores ->
-// barrier Y (image complete; every wave's DMA pieces of tile t + 1 have landed: s_waitcnt vmcnt(0) before it) -> gathers.  Saturated
+// barrier Y (image complete; every wave's DMA pieces of tile t + 1 have landed: each wave waited for its own at the TOP of the tile,
+// half a tile after requesting them, see "Vector-memory pipeline" at the band loop) -> gathers.  Saturated
 // tiles: one barrier.  The DMA runs up to two tiles ahead: tile t + 2 is requested right after barrier Y of tile t (top of a
 // saturated tile t) into slot (t + 2) % 3 = (t - 1) % 3, whose last readers are the P.V products of tile t - 1, which every wave has
 // retired (lgkmcnt(0)) before a barrier that the requesting wave has passed; its pieces are waited for (vmcnt(0)) before a barrier
@@ -39,6 +40,15 @@ template <typename T> struct WgFrag<true, T> { typedef f16x8s type; };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+// The same request with the address as (wave-uniform SGPR base) + (32-bit per-lane offset register).  Written as asm because the
+// builtin's address lands in a temporary VGPR pair inside loops (the zero-extension of the lane offset is hoisted out of the block and
+// the saddr form no longer matches), and the compiler guards every later write to an LDS-DMA's address registers with a vmcnt(0): here
+// the lane offset register is loop-invariant and never rewritten.  The compiler does not count these requests: its own vmcnt waits can
+// only come out stricter than needed, and every reader of the landed bytes sits behind an explicit vmcnt wait + workgroup barrier.
+__device__ __forceinline__ void glds16_sv(const unsigned char* ubase, unsigned lane_off, void* l) {
+    const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)l;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(lane_off), "s"(ubase) : "memory");
 }
 __device__ __forceinline__ void wave_lds_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -63,7 +73,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
 // one wave is in the matrix-heavy phase while its partner is in the VALU / LDS-heavy one (the staggered-wave-group idea of gemm256s.hip).
 // VGL (split units, NW = 4): only K goes through the ring (8 KiB per tile = two DMA pieces per wave); V^T fragments are loaded per wave
 // from global memory.  80 KiB of LDS: TWO workgroups of four waves per CU, i.e. the two waves of a SIMD belong to different workgroups.
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false>
+// DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them).
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     static_assert(!STAG || (NW == 8 && !KVG), "the stagger pairs the two 4-wave halves of an 8-wave workgroup");
     static_assert(!VGL || (SPLIT && NW == 4 && !KVG && !STAG), "V^T from global: the 4-wave split-unit variant");
@@ -136,6 +147,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
         idx = idx < 0 ? 0 : (idx > otab_max ? otab_max : idx);
         return a.otab[idx];
     };
+    auto block_x = [&](int qb, int t) -> int {                    // the PQ-layout offset only (one register to carry a tile ahead)
+        int idx = qb - 32 * t - 31 + c + Sp - 1 + 64;
+        idx = idx < 0 ? 0 : (idx > otab_max ? otab_max : idx);
+        return reinterpret_cast<const int*>(a.otab)[2 * idx];
+    };
+    auto pk_of_pq = [&](int x) -> int {                           // same table row in the PK layout: its slot within the 32-row unit is pi32-permuted
+        constexpr int SH = sizeof(T) == 4 ? 5 : 4;               // log2(bytes of one 8-element row entry)
+        const int r = (x >> SH) & 31;
+        return x + ((glc_pi32(r) - r) << SH);
+    };
     auto load_rows = [&](const unsigned char* base, int off, frag_t (&f)[4]) {       // 4 fragment units of gathered table rows
 #pragma unroll
         for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + off + s * UNITB);
@@ -167,6 +188,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = (f32x4){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
     };
     // LDS-DMA of key tile t into ring slot t % 3: piece p = 2 wave + i is 1 KiB of [K tile | V^T tile]
+    const unsigned dma_lane_off = lane * (SPLIT ? 32 : 16);
+    auto uniform_ptr = [](const unsigned char* q) -> const unsigned char* {       // tell the compiler what it cannot prove: wave-uniform, lives in SGPRs
+        const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+    };
     auto dma_tile = [&](int t) {
         if constexpr (KVG) return;
         unsigned char* slot = kv_ring + (size_t)(t % 3) * SLOTB;
@@ -175,12 +202,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             const int p = 2 * wave + i;
             if constexpr (SPLIT) {
                 // piece p = (unit `wave` of [K | V^T], part i): every lane fetches the hi (i = 0) or lo (i = 1) 16 bytes of ITS 32-byte
-                // entry, so the unit lands as [64 x hi | 64 x lo] (the per-lane source address makes the DMA a gather)
+                // entry, so the unit lands as [64 x hi | 64 x lo] (the per-lane source address makes the DMA a gather).
+                // Address = wave-uniform base + the loop-invariant lane offset register: a per-tile address register would be dead
+                // right after the request, and the compiler guards the re-use of an LDS-DMA's address registers with a vmcnt(0).
                 const unsigned char* ubase = (VGL || wave < 4) ? Kg + (size_t)t * TILEB + wave * UNITB : Vg + (size_t)t * TILEB + (wave - 4) * UNITB;
-                glds16(ubase + lane * 32 + i * 16, slot + p * 1024);
+                glds16_sv(uniform_ptr(ubase + i * 16), dma_lane_off, slot + p * 1024);
             } else {
-                const unsigned char* src = (p < NPIECE / 2 ? Kg + (size_t)t * TILEB + p * 1024 : Vg + (size_t)t * TILEB + (p - NPIECE / 2) * 1024) + lane * 16;
-                glds16(src, slot + p * 1024);
+                glds16_sv(uniform_ptr(p < NPIECE / 2 ? Kg + (size_t)t * TILEB + p * 1024 : Vg + (size_t)t * TILEB + (p - NPIECE / 2) * 1024), dma_lane_off, slot + p * 1024);
             }
         }
     };
@@ -340,13 +368,38 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
         }
         // One band tile.  xr is a literal at both call sites (the loop is unrolled by two).  `pq` holds the rows of this wave's LOW
         // block for tile kt, requested one tile ago: it is re-loaded IN PLACE for tile kt + 1 as soon as its last MFMA has issued.
+        // Vector-memory pipeline of the loop (every request has a whole phase to land; no wait sits right behind its own request):
+        //   top of tile kt   wait for everything requested during tile kt - 1: the PQ rows of this tile, the offset-table entries of
+        //                    tile kt + 1 and this wave's DMA pieces of key tile kt + 1 (requested after barrier Y, ~half a tile ago);
+        //                    request the offset-table entries of tile kt + 2
+        //   after S^T        request the PK rows of L(kt + 1) (used after barrier Y and the gather; they take the registers K(kt) has
+        //                    just left) and the PQ rows of tile kt + 1 in place;  barrier Y is an LDS-only barrier (the DMA was waited for above:
+        //                    every wave is past its own wait when it arrives), then the DMA of tile kt + 2 goes out
+        // Before: the entries were fetched where they were used (a dependent-load stall per tile), the rows right before barrier Y,
+        // whose vmcnt(0) then waited for them, and the DMA was waited for right after its request by the PK rows' own wait.
+        unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tiles = 0, tlast = 0;
+        const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
+        auto stamp = [&](int k) __attribute__((always_inline)) {      // time since the previous stamp goes to segment k (k < 0: start)
+            if constexpr (DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (k >= 0) seg[k] += t - tlast;
+                tlast = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         frag_t pq[4], pqx[4];
         load_rows(PQg, block_delta(q0, kt_a).x, pq);
         if ((kt_a % NSH) == wl) load_rows(PQg, block_delta(QX, kt_a).x, pqx);
+        int od_n = block_x(q0, kt_a + 1);                       // PQ-layout row offsets of the NEXT tile's low block
         auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
             const bool extra = (kt % NSH) == wl;                // wave-uniform: this wave also computes the block nobody owns
+            stamp(-1);
+            if constexpr (!KVG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(0);                                           // seg 0: wait for last tile's requests
             frag_t pk[4];
-            load_rows(PKg, block_delta(q0, kt + 1).y, pk);     // PK rows of L(kt + 1): consumed after the gather
+            const int od = od_n;
+            od_n = block_x(q0, kt + 2);
             if constexpr (!KVG) k_tile(kt, kf);
             float* img = p2c_img + (KVG ? (size_t)(kt & 1) * 32 * LROWP : (size_t)grp * 32 * LROWP);      // KVG: two images, alternating; STAG: one per half
             // the gathered c2p band is the initial accumulator of S^T; reg i <-> key k0 + 16 (i>>3) + 8h + (i&7)
@@ -373,16 +426,28 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
             // requests for the next tile, into the registers whose last MFMA has just issued
-            load_rows(PQg, block_delta(q0, kt + 1).x, pq);
-            if (((kt + 1) % NSH) == wl) load_rows(PQg, block_delta(QX, kt + 1).x, pqx);
+            // (request order pinned — conditional rows, PK rows, PQ rows, later the DMA: the PK rows are consumed first, and the wait the
+            // compiler places there counts the younger requests; a conditional request between them made that wait a vmcnt(0))
+            __builtin_amdgcn_sched_barrier(0);
+            if (((kt + 1) % NSH) == wl) load_rows(PQg, block_x(QX, kt + 1), pqx);    // (one tile in NSH: a dependent load, not carried)
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(PKg, pk_of_pq(od), pk);                   // PK rows of L(kt + 1), into the registers K(kt) has just left: consumed after the gather
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(PQg, od, pq);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(1);                                           // seg 1: K fragments, c2p gather, p2c + S^T MFMA issue, row requests
             if constexpr (KVG) k_tile(kt + 1 < nkt ? kt + 1 : kt, kf);     // in place: K(kt + 1)
             else if constexpr (!STAG) wg_barrier_lds();         // X: every wave has finished gathering the previous tile's image
+            stamp(2);                                           // seg 2: barrier X
             // (STAG: the barrier that ended this half's previous P2 already separates those gathers from these stores)
             band_store(img + c * LROWP + 32 * wl, bacc);        // row = key lane (conflict-free); the gather applies pi
             if (extra) band_store(img + c * LROWP + 32 * NSH, bacc2);
-            if constexpr (KVG) wg_barrier_lds();                // Y: image complete (the other image is still being gathered by slower waves)
-            else wg_barrier_all();                              // Y: image complete; tile kt + 1 is in the ring for everyone
-            if (kt + 2 < nkt) dma_tile(kt + 2);                 // slot (kt - 1) % 3: every wave is past tile kt - 1
+            wg_barrier_lds();                                   // Y: image complete; tile kt + 1 is in the ring for everyone (each wave waited for its pieces at the top)
+            stamp(3);                                           // seg 3: image stores (wait for the p2c MFMA results) + barrier Y
+            if constexpr (KVG) { if (kt + 2 < nkt) dma_tile(kt + 2); }
+            else dma_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);     // slot (kt - 1) % 3: every wave is past tile kt - 1.  Unconditional (past the end: the
+                                                                // last tile once more, into a slot nobody reads again) so that the request count is fixed
+            __builtin_amdgcn_sched_barrier(0);                  // (the PK-row MFMAs stay below: their rows were requested half a phase ago)
             float sv[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -395,8 +460,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], cacc);             // c2p of L(kt + 1)  [rr][query c]
+            stamp(4);                                           // seg 4: DMA request, image gather (waits for S^T), c2p MFMA issue
             softmax_pv(sv, kt);
             band_store(c2p_l + c * LROW + (xr ^ 32), cacc);     // over the old high block (its gather is long retired)
+            stamp(5);                                           // seg 5: softmax, P.V, c2p block store
+            if constexpr (DIAG) ++tiles;
             if constexpr (STAG) wg_barrier_lds();               // end of P2: this half's image may be rewritten; V^T(kt) is retired
         };
         if constexpr (STAG) { if (grp == 1) wg_barrier_lds(); } // the late half starts one phase later
@@ -407,6 +475,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             if (++kt >= kt_b) break;
         }
         if constexpr (STAG) { if (grp == 0) wg_barrier_lds(); } // ... and the early half waits for it at the end
+        if constexpr (DIAG) {
+            if (a.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {     // 64 workgroups of XCD 0
+                unsigned long long* o = a.stamps + ((size_t)(blockIdx.x >> 3) * NW + wave) * 8;
+                for (int k = 0; k < 6; ++k) o[k] = seg[k];
+                // s_memtime ticks per 100 MHz s_memrealtime tick over the band loop, x1000 (i.e. the clock s_memtime counts, in 0.1 MHz)
+                const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk0, dr = __builtin_amdgcn_s_memrealtime() - rt0;
+                o[6] = dr ? dc * 1000 / dr : 0; o[7] = tiles;
+            }
+        }
     }
 
     sat_tiles(kt_b, nkt, 0);
@@ -449,19 +526,19 @@ template <typename T, bool SPLIT, int NW, bool KVG, bool STAG, bool VGL> constex
                 : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> raised{0};
     constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG, VGL>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
     static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL>, 64 * NW, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG>, 64 * NW, lds);
         fprintf(stderr, "[attn_wg] NW=%d lds=%zu bytes, occupancy API: %d workgroup(s) per CU\n", NW, lds, nb);
     }
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
     return nullptr;
 }
 
@@ -471,9 +548,11 @@ template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL 
 const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a) {
     if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(wg): null pointer";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(wg): bad shape";
-    if (a.sel_b || a.stamps) return "attention(wg): no row selection / stamps in this kernel";
+    if (a.sel_b) return "attention(wg): no row selection in this kernel";
+    if (a.stamps && !(dtype == GLC_DT_F32 && a.split && !(a.variant & 57))) return "attention(wg): the stamped build exists for the split-f16 8-wave kernel only";
     if (dtype == GLC_DT_F32) {
         if (!a.split) return "attention(wg): the fp32 mode runs this kernel on split-f16 units only";
+        if (a.stamps) return launch_wg<float, true, 8, false, false, false, true>(st, a);
         // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
         static const bool stag_default = getenv("GLC_ATTN_STAG") != nullptr && atoi(getenv("GLC_ATTN_STAG")) != 0;
         if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);

@@ -1159,6 +1159,26 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         for (size_t i = 0; i < n; ++i) { s1 += h[i]; s2 += (double)h[i] * h[i]; }
         checksum[0] = s1; checksum[1] = s2;
     }
+    if (stamps && wg && sp && !(variant & 57)) {       // the split-f16 workgroup kernel, stamped build: 64 workgroups x 8 waves x 8 counters
+        unsigned long long* dbuf = nullptr;
+        const size_t ns = 64 * 8 * 8;
+        if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
+            AttnArgs as = a; as.stamps = dbuf;
+            const char* m = glc_launch_attention_wg(st, e->dtype, as);
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> hs(ns);
+            if (!m && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double s[8] = {0};
+                for (size_t i = 0; i < 64 * 8; ++i) for (int k = 0; k < 8; ++k) s[k] += (double)hs[i * 8 + k];
+                const double nt = s[7] > 0 ? s[7] : 1;
+                fprintf(stderr, "[attn_wg stamps] per band tile per wave (s_memtime ticks), %.0f tiles: request wait %.0f | K+gather+p2c/S issue %.0f | barrier X %.0f | "
+                                "image stores + barrier Y %.0f | DMA, image gather, c2p issue %.0f | softmax + P.V + c2p store %.0f | total %.0f | s_memtime clock %.0f MHz\n",
+                        nt, s[0] / nt, s[1] / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / nt, s[6] / (64 * 8) / 10.0);
+            } else if (m) fprintf(stderr, "[attn_wg stamps] %s\n", m);
+            (void)hipFree(dbuf);
+        }
+    }
     if (stamps && !wg && !sp) {
         unsigned long long* dbuf = nullptr;
         const size_t ns = 64 * 4 * 8;

@@ -56,6 +56,10 @@ struct LayerW {
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr; // f32
     void *PK = nullptr, *PQ = nullptr;                                        // T [nh, P, 64]
     void *PKs = nullptr, *PQs = nullptr;                                      // fp32 mode: the same tables as split-f16 units (band kernel, AttnArgs::split)
+    // LayerNorm folded into the group-split GEMMs (GemmArgs::a_stats): W1 . diag(ln1 gamma), Wqkv . diag(previous layer's ln2 gamma)
+    // as group-split rows, their row sums c and the folded biases d = W beta + b
+    void *W1f = nullptr, *Wqkvf = nullptr;
+    float *c1 = nullptr, *d1 = nullptr, *cq = nullptr, *dq = nullptr;
 };
 
 }  // namespace
@@ -69,6 +73,8 @@ struct glc_engine {
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
     bool last_gs = false;           // the last forward ran the group-split pipeline
+    bool ln_fused = true;           // group-split pipeline: LayerNorm folded into the GEMMs around it (GLC_LNF=0: separate LayerNorm kernels)
+    float2 *statsA = nullptr, *statsB = nullptr, *ln_part = nullptr;     // (mean, rstd) per row of X / H1 when they hold raw sums; the producers' partials
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
@@ -195,6 +201,11 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
+        if (e->dtype == GLC_F32) {             // (small; kept whether or not the fold is switched on: glc_debug_set_ln_fused)
+            dfree(e, e->statsA); e->statsA = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsA) return false;
+            dfree(e, e->statsB); e->statsB = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsB) return false;
+            dfree(e, e->ln_part); e->ln_part = (float2*)dmalloc(e, (size_t)Mpad * ((c.hidden + 63) / 64) * sizeof(float2)); if (!e->ln_part) return false;
+        }
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
         e->capM = Mpad;
         e->hidden_cap = 0;   // dump buffer is re-made lazily
@@ -436,13 +447,20 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
       else KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
 
+    bool x_is_raw = false;
     for (int l = 0; l < c.layers; ++l) {
         const LayerW& w = e->layers[l];
         const bool last = prune && l == c.layers - 1;
+        // LayerNorm folded away (group-split pipeline, e->ln_fused): X / H1 then hold the RAW residual sums of the producer GEMMs plus
+        // (mean, rstd) per row in statsA / statsB; the consumers run on weights with gamma folded in.  Normalised rows stay where a
+        // kernel outside the pipeline reads them: the embedding output (layer 0) and the input of the pruned last layer.
+        const bool lnf = gs && e->ln_fused && w.W1f && (l == 0 || w.Wqkvf);
+        const bool x_raw = x_is_raw;         // X holds raw sums + statsA (written by the previous layer's FFN2)
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit;
         if (last) break;
+        if (x_raw) { g.W = w.Wqkvf; g.bias = w.dq; g.a_stats = e->statsA; g.ln_c = w.cq; }
         { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         a.split = asplit; a.ctx_gs = gs;
@@ -452,17 +470,27 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         { Prof p(e, PC_ATTN); KCHK(launch_band(a), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
+        if (x_raw) { const LayerW& wp = e->layers[l - 1]; o.r_stats = e->statsA; o.r_gamma = wp.ln2g; o.r_beta = wp.ln2b; }
+        if (lnf) { o.C = e->H1; o.ln_part = e->ln_part; }      // raw sum -> H1 (group-split rows) + partials
         { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
-        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
-                                    : glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
+        { Prof p(e, PC_LN); KCHK(lnf ? glc_launch_ln_stats(st, e->ln_part, H / 64, e->statsB, M, H, c.ln_eps)
+                                 : gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
+                                      : glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
+        if (lnf) { f1.W = w.W1f; f1.bias = w.d1; f1.a_stats = e->statsB; f1.ln_c = w.c1; }
         { Prof p(e, PC_FFN1); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
+        if (lnf) { f2.r_stats = e->statsB; f2.r_gamma = w.ln1g; f2.r_beta = w.ln1b; }
+        // the next consumer of X takes raw rows only if it is a folded QKV of the pipeline (not the pruned last layer, which gathers normalised rows)
+        const bool next_raw = lnf && l + 1 < c.layers && e->layers[l + 1].Wqkvf && !(prune && l + 1 == c.layers - 1);
+        if (next_raw) { f2.C = e->X; f2.ln_part = e->ln_part; }
         { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
-        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H)
-                                    : glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
+        { Prof p(e, PC_LN); KCHK(next_raw ? glc_launch_ln_stats(st, e->ln_part, H / 64, e->statsA, M, H, c.ln_eps)
+                                 : gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H)
+                                      : glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
+        x_is_raw = next_raw;
         if (e->keep_hidden)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     }
@@ -679,6 +707,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
+    if (const char* lv = getenv("GLC_LNF")) e->ln_fused = atoi(lv) != 0;      // developer A/B switch
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
@@ -696,6 +725,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         if (hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) { set_err("event create failed"); break; }
         size_t stage_n = (size_t)cfg->vocab * H;
         if ((size_t)I * H > stage_n) stage_n = (size_t)I * H;
+        if (3 * (size_t)H * H > stage_n) stage_n = 3 * (size_t)H * H;     // the folded fused QKV weight goes up in one piece
         float* staging = nullptr;
         if (hipMalloc((void**)&staging, stage_n * sizeof(float)) != hipSuccess) { set_err("staging alloc failed"); break; }
         auto fail = [&]() { (void)hipFree(staging); };
@@ -768,6 +798,42 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 g.Qh = w.PQs; g.Kh = w.PKs; g.qkv_split = 1;
                 gm = glc_launch_gemm_auto(e->stream, dtype, EPI_QKV, g);
                 if (gm) { set_err(gm); lok = false; }
+            }
+            if (lok && e->ln_fused && e->w_presplit && dtype == GLC_F32) {
+                // LayerNorm folded into the consumer GEMMs of the group-split pipeline (GemmArgs::a_stats):
+                //   W1' = W1 diag(gamma1), c1 = W1' 1, d1 = W1 beta1 + b1            (this layer's ln1 feeds its FFN1)
+                //   Wqkv' = Wqkv diag(gamma2 of layer l - 1), cq, dq likewise          (the previous layer's ln2 feeds this QKV; layer 0
+                //   reads the embedding LayerNorm's output, which stays a kernel of its own)
+                std::vector<float> wf((size_t)(I > 3 * H ? I : 3 * H) * H), cv(I > 3 * H ? I : 3 * H), dv(cv.size());
+                auto fold = [&](const float* Wsrc, int rows, const float* gam, const float* bet, const float* b0, int row0) {
+                    for (int n = 0; n < rows; ++n) {
+                        double cs = 0.0, ds = 0.0;
+                        const float* wr = Wsrc + (size_t)n * H;
+                        float* o = wf.data() + (size_t)(row0 + n) * H;
+                        for (int k = 0; k < H; ++k) { const float f = wr[k] * gam[k]; o[k] = f; cs += (double)f; ds += (double)bet[k] * (double)wr[k]; }
+                        cv[row0 + n] = (float)cs; dv[row0 + n] = (float)(ds + (double)b0[row0 + n]);
+                    }
+                };
+                fold(t[10], I, t[8], t[9], t[11], 0);
+                w.W1f = dmalloc(e, (size_t)I * H * es, false);
+                if (!w.W1f || !upload_as(e, wf.data(), (size_t)I * H, w.W1f, staging)) { lok = false; break; }
+                const char* pm = glc_launch_presplit(e->stream, w.W1f, (size_t)I * H);
+                if (pm) { set_err(pm); lok = false; break; }
+                w.c1 = upload_f32(e, cv.data(), I); w.d1 = upload_f32(e, dv.data(), I);
+                if (!w.c1 || !w.d1) { lok = false; break; }
+                if (l > 0) {
+                    const float* const* tp = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * (l - 1);
+                    fold(wq.data(), H, tp[14], tp[15], bqkv.data(), 0);       // wq / bqkv still hold this layer's scaled query projection
+                    fold(t[2], H, tp[14], tp[15], bqkv.data(), H);
+                    fold(t[4], H, tp[14], tp[15], bqkv.data(), 2 * H);
+                    w.Wqkvf = dmalloc(e, 3 * (size_t)H * H * es, false);
+                    if (!w.Wqkvf || !upload_as(e, wf.data(), 3 * (size_t)H * H, w.Wqkvf, staging)) { lok = false; break; }
+                    pm = glc_launch_presplit(e->stream, w.Wqkvf, 3 * (size_t)H * H);
+                    if (pm) { set_err(pm); lok = false; break; }
+                    w.cq = upload_f32(e, cv.data(), 3 * (size_t)H); w.dq = upload_f32(e, dv.data(), 3 * (size_t)H);
+                    if (!w.cq || !w.dq) { lok = false; break; }
+                }
+                if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // host vectors are reused
             }
         }
         if (!lok) { fail(); break; }
@@ -1030,6 +1096,14 @@ int glc_debug_set_group_split(glc_engine* e, int mode) {
     return 0;
 }
 int glc_debug_last_forward_group_split(const glc_engine* e) { return e ? (e->last_gs ? 1 : 0) : -1; }
+/* Group-split pipeline with LayerNorm folded into the GEMMs (1, default) or as kernels of its own (0).  The folded weights are built
+ * at load unless GLC_LNF=0 was set then; without them the switch has no effect. */
+int glc_debug_set_ln_fused(glc_engine* e, int on) {
+    if (!e) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->ln_fused = on != 0;
+    return 0;
+}
 int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hidden = on != 0; return 0; }
 int glc_engine_set_prune_last_layer(glc_engine* e, int on) { if (!e) return -1; e->prune_last = on != 0; return 0; }
 int glc_debug_set_attention_impl(glc_engine* e, int impl) {

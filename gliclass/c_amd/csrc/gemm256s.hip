@@ -267,14 +267,50 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
             if (bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + j * 16 + 4 * g); bj[j][0] = bv[0]; bj[j][1] = bv[1]; bj[j][2] = bv[2]; bj[j][3] = bv[3]; }
             else { bj[j][0] = bj[j][1] = bj[j][2] = bj[j][3] = 0.f; }
         }
+        // LayerNorm folded into this GEMM (GemmArgs::a_stats): the accumulator is raw_row . (W diag(gamma))^T; the lane's 8 accumulator
+        // rows are m0 + 128 wm + 16 i + r16
+        const bool lnf = GS && EPI != EPI_RESID && p.a_stats != nullptr;
+        float cj[GS ? 4 : 1][4];
+        float2 st_i[GS ? 8 : 1];
+        if constexpr (GS && EPI != EPI_RESID) {
+            if (lnf) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const f32x4 cv = *reinterpret_cast<const f32x4*>(p.ln_c + n0 + wn * 64 + j * 16 + 4 * g); cj[j][0] = cv[0]; cj[j][1] = cv[1]; cj[j][2] = cv[2]; cj[j][3] = cv[3]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st_i[i] = p.a_stats[m0 + wm * 128 + i * 16 + r16];
+            }
+        }
+        // EPI_RESID with GemmArgs::r_stats: the residual rows are raw, LayerNorm is applied on the fly; this lane's 8 columns
+        float rg[GS ? 8 : 1], rb[GS ? 8 : 1];
+        const bool rln = GS && EPI == EPI_RESID && p.r_stats != nullptr;
+        const bool gsout = GS && EPI == EPI_RESID && p.ln_part != nullptr;     // raw GS rows + statistics partials out (non-wide lane map)
+        if constexpr (GS && EPI == EPI_RESID) {
+            if (rln) {
+                const int nb = n0 + wn * 64 + (gsout ? (lane & 7) * 8 : (lane & 7) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rg[e] = p.r_gamma[nb + e]; rb[e] = p.r_beta[nb + e];
+                    rg[4 + e] = p.r_gamma[nb + (gsout ? 4 : 32) + e]; rb[4 + e] = p.r_beta[nb + (gsout ? 4 : 32) + e];
+                }
+            }
+        }
         // residual rows are fetched one 32-row chunk AHEAD of their use (16-byte coalesced loads): without this each
         // chunk exposed a full HBM round trip between its LDS read-back and its store (+4.7 us per tile measured)
         vec8T rpre[4], rpre_lo[GS ? 4 : 1];
-        auto load_resid = [&](int c, vec8T (&r)[4], vec8T (&rl)[GS ? 4 : 1]) {
+        float2 rst_pre[GS ? 4 : 1];
+        auto load_resid = [&](int c, vec8T (&r)[4], vec8T (&rl)[GS ? 4 : 1], float2 (&rst)[GS ? 4 : 1]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
                 if constexpr (GS) {
+                    if (rln) rst[k] = p.r_stats[m0 + wm * 128 + c * 32 + row];
+                    if (gsout) {                 // 8 consecutive columns per lane (GS residual rows only: the fused pipeline never mixes in plain ones)
+                        const int n = n0 + wn * 64 + g8 * 8;
+                        const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
+                        r[k] = *reinterpret_cast<const vec8T*>(rp);
+                        rl[k] = *reinterpret_cast<const vec8T*>(rp + 32);
+                        continue;
+                    }
                     // "wide" lane map of the fp32-row epilogue: a lane owns columns [4 g8, +4) and [32 + 4 g8, +4) of the wave's 64, so that
                     // each store / load instruction covers whole 128-byte row segments (8 floats per lane left 16-byte holes: +8 % per GEMM)
                     const int na = n0 + wn * 64 + g8 * 4;
@@ -296,20 +332,28 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 }
             }
         };
-        if (EPI == EPI_RESID) load_resid(0, rpre, rpre_lo);
+        if (EPI == EPI_RESID) load_resid(0, rpre, rpre_lo, rst_pre);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             vec8T rcur[4], rcur_lo[GS ? 4 : 1];
+            float2 rst_cur[GS ? 4 : 1];
             if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { rcur[k] = rpre[k]; if constexpr (GS) rcur_lo[k] = rpre_lo[k]; }
-                if (c + 1 < 4) load_resid(c + 1, rpre, rpre_lo);
+                for (int k = 0; k < 4; ++k) { rcur[k] = rpre[k]; if constexpr (GS) { rcur_lo[k] = rpre_lo[k]; rst_cur[k] = rst_pre[k]; } }
+                if (c + 1 < 4) load_resid(c + 1, rpre, rpre_lo, rst_pre);
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = acc[2 * c + ii][j];
+                    if constexpr (GS && EPI != EPI_RESID) {
+                        if (lnf) {
+                            const float2 sm = st_i[2 * c + ii];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = sm.y * (v[r] - sm.x * cj[j][r]);
+                        }
+                    }
                     v[0] += bj[j][0]; v[1] += bj[j][1]; v[2] += bj[j][2]; v[3] += bj[j][3];
                     if (EPI == EPI_GELU) {
                         if constexpr (GS) {     // fp32 mode: the erf form at fp32 resolution (the 16-bit epilogue's logistic fit is only f16-exact)
@@ -326,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
-                constexpr bool wide = GS && EPI == EPI_RESID;      // fp32 row output: see load_resid
+                const bool wide = GS && EPI == EPI_RESID && !gsout;      // fp32 row output: see load_resid
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 68 + (wide ? g8 * 4 : g8 * 8));
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 68 + (wide ? 32 + g8 * 4 : g8 * 8 + 4));
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -334,12 +378,37 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 const int n = n0 + wn * 64 + (wide ? g8 * 4 : g8 * 8);
                 if (EPI == EPI_RESID) {
                     if (GS && p.gs_resid_plain) {
-                        const f32x4 ra = __builtin_bit_cast(f32x4, rcur[k]), rb = __builtin_bit_cast(f32x4, rcur_lo[GS ? k : 0]);
+                        const f32x4 ra = __builtin_bit_cast(f32x4, rcur[k]), rb4 = __builtin_bit_cast(f32x4, rcur_lo[GS ? k : 0]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb[e]; }
+                        for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb4[e]; }
+                    } else if (GS && rln) {     // raw residual row: LayerNorm on the fly
+                        const float2 sm = rst_cur[GS ? k : 0];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float r = (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e];
+                            v[e] += (r - sm.x) * sm.y * rg[GS ? e : 0] + rb[GS ? e : 0];
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += GS ? (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e] : (float)rcur[k][e];
+                    }
+                }
+                if constexpr (GS && EPI == EPI_RESID) {
+                    if (gsout) {
+                        // raw GS row out + this 64-column block's (sum, sum of squares) of the row: the 8 lanes of a row are consecutive
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                        if (g8 == 0) p.ln_part[(size_t)m * (N >> 6) + ((n0 + wn * 64) >> 6)] = make_float2(s1, s2);
+                        vec8T oh, ol2;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { oh[e] = (T)v[e]; ol2[e] = (T)(v[e] - (float)oh[e]); }
+                        T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * N + (n >> 5) * 64 + (n & 31);
+                        *reinterpret_cast<vec8T*>(cp) = oh;
+                        *reinterpret_cast<vec8T*>(cp + 32) = ol2;
+                        continue;
                     }
                 }
                 vec8T o, ol;
@@ -377,9 +446,14 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         }
     } else {
         // V third: D[m = 16i + 4g + r][n = 16j + r16]; patch [64 rows dd][32 cols key], row stride 36 floats
-        float bn[4];
+        float bn[4], cn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) bn[j] = bias ? bias[n0 + wn * 64 + j * 16 + r16] : 0.f;
+        const bool lnf = GS && p.a_stats != nullptr;       // LayerNorm folded into this GEMM (GemmArgs::a_stats)
+        if (lnf) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cn[j] = p.ln_c[n0 + wn * 64 + j * 16 + r16];
+        }
         const int hh = (n0 + wn * 64 - 2 * p.H) >> 6;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -388,6 +462,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = acc[2 * c + ii][j];
+                    if (lnf) {      // accumulator rows m0 + 128 wm + 16 (2c + ii) + 4g + r
+                        const float2* sp = p.a_stats + m0 + wm * 128 + (2 * c + ii) * 16 + 4 * g;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float2 sm = sp[r]; v[r] = sm.y * (v[r] - sm.x * cn[j]); }
+                    }
                     v[0] += bn[j]; v[1] += bn[j]; v[2] += bn[j]; v[3] += bn[j];
                     *reinterpret_cast<f32x4*>(stg + (j * 16 + r16) * 36 + ii * 16 + 4 * g) = v;
                 }

@@ -106,6 +106,17 @@ __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restri
     if (row >= M) return;
     ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
 }
+// LayerNorm statistics from the producer GEMM's partials (GemmArgs::ln_part)
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int nparts, float2* __restrict__ stats, int M, double invH, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) { const float2 v = part[(size_t)row * nparts + i]; s += (double)v.x; q += (double)v.y; }
+    const double mean = s * invH;
+    double var = q * invH - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[row] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, f16_t* __restrict__ X,
@@ -378,6 +389,12 @@ const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, con
     if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm_gs: bad args";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "layernorm_gs: unsupported hidden size";
     hipLaunchKernelGGL(layernorm_gs_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
+    return nullptr;
+}
+
+const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps) {
+    if (!part || !stats || M <= 0 || H <= 0 || nparts <= 0 || nparts > 1024) return "ln_stats: bad args";
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, nparts, stats, M, 1.0 / (double)H, eps);
     return nullptr;
 }
 

@@ -134,6 +134,9 @@ int glc_debug_set_attention_impl(glc_engine* e, int impl);
  * kernel).  mode 0 off, 1 auto (default: forwards large enough to fill the chip), 2 whenever the shapes allow (tests). */
 int glc_debug_set_group_split(glc_engine* e, int mode);
 int glc_debug_last_forward_group_split(const glc_engine* e);
+/* Group-split pipeline: LayerNorm folded into the GEMMs around it (1, default: the producer writes raw rows + row statistics, the consumer
+ * runs on weights with gamma folded in and finishes (LN(x) W^T + b) in its epilogue) or as kernels of its own (0). */
+int glc_debug_set_ln_fused(glc_engine* e, int on);
 
 /* clamp(bucket(q-k)+span, 0, 2span-1) for q-k in [-(S-1), S-1] at out[q-k+S-1] (float32 math as
  * torch).  Pure host function (no GPU needed). */

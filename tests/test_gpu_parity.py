@@ -402,7 +402,10 @@ def test_length_bucketing_preserves_results(dtype, engines, weights_for):
     got = eng.forward(ids, mask)
     assert eng.L.glc_debug_last_forward_groups(eng.h) >= 2          # the plan really split this batch
     assert got.shape == one.shape and eng.last_c == 3
-    tol = 1e-5 if dtype == "f32" else 5e-3             # 16-bit: a different padded length moves tile boundaries (rounding only)
+    # f32: the groups are small enough for the plain-fp32 128-tile pipeline while the single batch runs the group-split one with
+    # LayerNorm folded into its GEMMs — same function, different rounding points, each ~1e-5 from the oracle (checked below);
+    # 16-bit: a different padded length moves tile boundaries (rounding only)
+    tol = 5e-5 if dtype == "f32" else 5e-3
     assert np.abs(sig(got) - sig(one)).max() <= tol
     if dtype == "f32":                                 # and against the oracle on a few rows (trimmed: rows are independent)
         for b in (0, 2, 19):                          # rows with 3, 1 and 2 labels
@@ -559,6 +562,16 @@ def test_group_split_pipeline_vs_oracle_and_plain_fp32(cname, engines, weights_f
             assert eng.last_group_split()
             assert np.isfinite(gs).all()
             assert np.abs(sig(gs) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
+            # ... and with LayerNorm as kernels of its own instead of folded into the GEMMs around it (raw rows + row statistics
+            # out of the producer, gamma-folded weights + epilogue correction in the consumer): same function, other rounding points
+            eng.set_ln_fused(False)
+            unf = eng.forward(ids, mask)
+            eng.set_ln_fused(True)
+            assert eng.last_group_split()
+            assert np.abs(sig(unf) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
+            assert np.abs(sig(gs) - sig(unf)).max() <= 1e-4, (B, S)
+            assert not np.array_equal(gs, unf), "the LayerNorm switch changed nothing: is the folded path running?"
             assert np.abs(sig(gs) - sig(plain)).max() <= 1e-4, (B, S)     # each sits ~1e-5 from the oracle; GS rows also carry 22 instead of 24 bits
     finally:
         eng.set_group_split(1)
+        eng.set_ln_fused(True)

@@ -59,7 +59,18 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int mt = tile / ntn, nt = tile % ntn;
+    int mt = tile / ntn, nt = tile % ntn;
+    // Wide N (FFN1: 12 N-tiles = 9.4 MB of W against a 4 MB L2 per XCD): walking a whole row of N-tiles before the next M-tile re-fetches
+    // every W tile for every ~3 M-tiles (FETCH_SIZE 1.25 GB per launch against 0.21 GB of operands).  Instead each XCD takes its share of
+    // the M-tiles and sweeps them once per group of <= 4 N-tiles, so the group's W tiles stay in its L2: W is fetched once per XCD and
+    // group, A once per group.
+    if (p.n_group > 0) {
+        const int mts = nwg / ntn, mpx = mts >> 3, nb = p.n_group;     // launcher: mts % 8 == 0, ntn % nb == 0
+        const int i = bid >> 3, per = mpx * nb;
+        const int cg = i / per, r = i - cg * per;
+        mt = xcd * mpx + r / nb;
+        nt = cg * nb + r % nb;
+    }
     const int m0 = mt * TM, n0 = (n_tile0 + nt) * TN;   // this launch covers n-tiles [n_tile0, n_tile0 + ntn)
 
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
@@ -504,7 +515,11 @@ template <typename T, int EPI, bool VMODE, bool GS = false> const char* launch_e
     static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
     if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
-    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS>), dim3(grid), dim3(512), NSLOT * STAGE, st, a, n_tile0, ntn);
+    GemmArgs b = a;
+    static const int ng_env = getenv("GLC_GEMM_NGROUP") ? atoi(getenv("GLC_GEMM_NGROUP")) : -1;      // developer A/B switch: 0 = row-major tile order
+    b.n_group = 0;
+    if (ng_env != 0 && ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);     // (6 N-tiles in 2 groups measured MORE fetch: A twice, W fitted anyway)
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
     return nullptr;
 }
 template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmArgs& a) {

@@ -32,6 +32,7 @@ struct GemmArgs {
     // gemm256s on group-split operands (glc_launch_gemm256s_gs): EPI_BIAS / EPI_GELU write C as plain fp32 rows instead of GS rows;
     // EPI_RESID reads its residual as plain fp32 rows instead of GS rows (decoder backbone: the residual stream itself)
     int gs_c_plain = 0, gs_resid_plain = 0;
+    int n_group = 0;                        // gemm256s, set by its launcher: tile order sweeps the M-tiles once per group of n_group N-tiles (0: row-major)
     // LayerNorm folded into the group-split GEMMs around it (glc_launch_gemm256s_gs; DESIGN.md "LayerNorm folded away").  The producer
     // (EPI_RESID) writes the RAW sum (GS rows, C) plus per-row partial (sum, sum of squares) of each 64-column block to ln_part
     // [Mpad][N / 64]; glc_launch_ln_stats turns them into (mean, rstd) per row.  A consumer whose A rows are such raw rows gets

@@ -264,7 +264,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         e->capSel = rsel;
     }
     {
-        const size_t nf = (size_t)B * (Sp >> 5);
+        const size_t nf = (size_t)round_up(B * Sp, 256) >> 5;      // one byte per 32-row tile of the padded row grid (the QKV GEMM reads 8 per 256-row tile)
         if (nf > e->capFlag) { dfree(e, e->tile_flag); e->tile_flag = (unsigned char*)dmalloc(e, nf); if (!e->tile_flag) return false; e->capFlag = nf; }
     }
     if (!e->dtabs.count(Sp)) {
@@ -506,11 +506,12 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; g.qkv_skip_q = band_sel ? 0 : 1;
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit && band_sel;
-        KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false);
-        if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)B * (Sp >> 5), st), false);
+        if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)Mpad >> 5, st), false);
         // (group-split pipeline: the compact rows leave it here — plain fp32, the rest of this layer runs on the small-M kernels)
         if (gs) KCHK(glc_launch_gather_rows_gs(st, e->X, e->cls_pos, ccap, (float*)e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         else KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
+        if (band_sel) g.q_tile_flag = e->tile_flag;       // the gather has flagged the query tiles that hold selected rows: the Q third skips the others
+        KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false);
         if (band_sel) {
             AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
             a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         nt = cg * nb + r % nb;
     }
     const int m0 = mt * TM, n0 = (n_tile0 + nt) * TN;   // this launch covers n-tiles [n_tile0, n_tile0 + ntn)
+    if constexpr (EPI == EPI_QKV && !VMODE) {
+        if (p.q_tile_flag && n0 < p.H) {                // Q third, pruned last layer: nobody reads query tiles without selected rows
+            const unsigned long long f8 = *reinterpret_cast<const unsigned long long*>(p.q_tile_flag + (m0 >> 5));
+            if (f8 == 0ull) return;                     // workgroup-uniform, before any barrier
+        }
+    }
 
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W);

@@ -33,6 +33,9 @@ struct GemmArgs {
     // EPI_RESID reads its residual as plain fp32 rows instead of GS rows (decoder backbone: the residual stream itself)
     int gs_c_plain = 0, gs_resid_plain = 0;
     int n_group = 0;                        // gemm256s, set by its launcher: tile order sweeps the M-tiles once per group of n_group N-tiles (0: row-major)
+    // QKV (gemm256s), pruned last layer: one byte per 32-row tile of the [Mpad] rows; a workgroup of the Q third whose 256 rows hold no
+    // flagged tile returns at once (only the query tiles with selected rows are ever read)
+    const unsigned char* q_tile_flag = nullptr;
     // LayerNorm folded into the group-split GEMMs around it (glc_launch_gemm256s_gs; DESIGN.md "LayerNorm folded away").  The producer
     // (EPI_RESID) writes the RAW sum (GS rows, C) plus per-row partial (sum, sum of squares) of each 64-column block to ln_part
     // [Mpad][N / 64]; glc_launch_ln_stats turns them into (mean, rstd) per row.  A consumer whose A rows are such raw rows gets

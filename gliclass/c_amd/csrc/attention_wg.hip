@@ -392,14 +392,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
         load_rows(PQg, block_delta(q0, kt_a).x, pq);
         if ((kt_a % NSH) == wl) load_rows(PQg, block_delta(QX, kt_a).x, pqx);
         int od_n = block_x(q0, kt_a + 1);                       // PQ-layout row offsets of the NEXT tile's low block
+        int odx_n = block_x(QX, kt_a + 1);                      // ... and of the unowned block (one wave per tile needs it: that wave would otherwise
+                                                                // sit in a dependent load right before barrier X, every tile, with all others waiting)
         auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
             const bool extra = (kt % NSH) == wl;                // wave-uniform: this wave also computes the block nobody owns
             stamp(-1);
             if constexpr (!KVG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(0);                                           // seg 0: wait for last tile's requests
             frag_t pk[4];
-            const int od = od_n;
+            const int od = od_n, odx = odx_n;
             od_n = block_x(q0, kt + 2);
+            odx_n = block_x(QX, kt + 2);
             if constexpr (!KVG) k_tile(kt, kf);
             float* img = p2c_img + (KVG ? (size_t)(kt & 1) * 32 * LROWP : (size_t)grp * 32 * LROWP);      // KVG: two images, alternating; STAG: one per half
             // the gathered c2p band is the initial accumulator of S^T; reg i <-> key k0 + 16 (i>>3) + 8h + (i&7)
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             // (request order pinned — conditional rows, PK rows, PQ rows, later the DMA: the PK rows are consumed first, and the wait the
             // compiler places there counts the younger requests; a conditional request between them made that wait a vmcnt(0))
             __builtin_amdgcn_sched_barrier(0);
-            if (((kt + 1) % NSH) == wl) load_rows(PQg, block_x(QX, kt + 1), pqx);    // (one tile in NSH: a dependent load, not carried)
+            if (((kt + 1) % NSH) == wl) load_rows(PQg, odx, pqx);
             __builtin_amdgcn_sched_barrier(0);
             load_rows(PKg, pk_of_pq(od), pk);                   // PK rows of L(kt + 1), into the registers K(kt) has just left: consumed after the gather
             __builtin_amdgcn_sched_barrier(0);

@@ -81,13 +81,28 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
     const int nqb = (Sp + 127) >> 7;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int bh = xcd + 8 * (jj / nqb);
-    const int q0 = ((jj % nqb) * 4 + wave) * 32;
-    if (bh >= a.B * a.nh || q0 >= Sp) return;  // whole wave leaves; no workgroup barriers below
+    int q0 = ((jj % nqb) * 4 + wave) * 32;
+    if (bh >= a.B * a.nh) return;              // whole workgroup leaves
     const int b = bh / a.nh, hh = bh - b * a.nh;
-    if (a.tile_flag && !a.tile_flag[(size_t)b * (Sp >> 5) + (q0 >> 5)]) return;   // pruned last layer: no selected row in this query tile
+    // Pruned last layer, cooperative form (a.ksplit): when exactly ONE of this workgroup's four query tiles holds selected rows — the usual
+    // case: [CLS] and the class tokens sit at the head of the sequence — the four waves share that tile and split its KEYS four ways
+    // (contiguous quarters of the key tiles), then merge their (m, l, O) partials through LDS.  A wave walking all key tiles of its tile
+    // alone, one wave per SIMD and nothing to overlap with, was half of the pruned layer's time.
+    int kpart = -1;                            // >= 0: this wave's quarter
+    if (a.tile_flag && a.ksplit) {
+        const unsigned char* tf = a.tile_flag + (size_t)b * (Sp >> 5) + (jj % nqb) * 4;
+        int cnt = 0, sel = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) if (((jj % nqb) * 4 + w) * 32 < Sp && tf[w]) { ++cnt; sel = w; }
+        if (cnt == 0) return;                  // workgroup-uniform
+        if (cnt == 1) { q0 = ((jj % nqb) * 4 + sel) * 32; kpart = wave; }
+    }
+    if (q0 >= Sp) return;                      // whole wave leaves; no workgroup barriers below (cooperative form: q0 < Sp for all four)
+    if (kpart < 0 && a.tile_flag && !a.tile_flag[(size_t)b * (Sp >> 5) + (q0 >> 5)]) return;   // pruned last layer: no selected row in this query tile
     if (q0 >= a.klen[b] && q0 > 0) {
         // every query of this tile lies past the row's last attended token: a padding-only tile of a ragged batch.  Its
         // output never reaches an attended row (those keys are masked), so skip the work and store zeros (finite).
+        if (kpart > 0) return;                 // cooperative form: one wave stores
         T* outz = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + c) * a.H + hh * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -256,8 +271,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
     kt_a = kt_a > nkt ? nkt : kt_a;
     int kt_b = (q0 + 31 - a.rsat_neg + 31) / 32;
     kt_b = kt_b < kt_a ? kt_a : (kt_b > nkt ? nkt : kt_b);
+    // cooperative form: this wave's quarter [k_lo, k_hi) cuts the three ranges; an empty quarter leaves m = -3e38, l = 0, O = 0
+    const int k_lo = kpart < 0 ? 0 : (nkt * kpart) >> 2, k_hi = kpart < 0 ? nkt : (nkt * (kpart + 1)) >> 2;
+    const int s0_hi = kt_a < k_hi ? kt_a : k_hi, s1_lo = kt_b > k_lo ? kt_b : k_lo;
+    kt_a = kt_a > k_lo ? kt_a : k_lo;
+    kt_b = kt_b < k_hi ? kt_b : k_hi;
 
-    sat_tiles(0, kt_a, a.P - 1);
+    sat_tiles(k_lo, s0_hi, a.P - 1);
 
     if (kt_a < kt_b) {
     // Fragment sets are addressed STATICALLY (runtime-indexed register arrays would go to scratch).  The default build
@@ -413,7 +433,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
     }
     }
 
-    sat_tiles(kt_b, nkt, 0);
+    sat_tiles(s1_lo, k_hi, 0);
 
     if constexpr (DIAG) {
         if (a.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {     // 64 blocks of XCD 0
@@ -423,6 +443,34 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_band_kernel(
         }
     }
     l += __shfl_xor(l, 32, 64);
+    if (kpart >= 0) {
+        // merge the four key quarters: M = max m_j, L = sum l_j 2^(m_j - M), O = sum O_j 2^(m_j - M).  The band scratch is dead; every
+        // wave parks (m, l, O) in its own 8.5 KiB of it, wave 0 folds the other three in and stores.
+        float* park = lds + (size_t)wave * 2 * 32 * LROW;          // 34 floats per lane, lane-major (conflict-free)
+        __syncthreads();                                            // (all four waves are here: same q0, same branches above)
+        if (wave > 0) {
+            park[lane] = m; park[64 + lane] = l;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { park[(2 + i) * 64 + lane] = o0[i]; park[(18 + i) * 64 + lane] = o1[i]; }
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        float mj[3], M = m;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { mj[j] = lds[(size_t)(j + 1) * 2 * 32 * LROW + lane]; M = fmaxf(M, mj[j]); }
+        const float f0 = __builtin_amdgcn_exp2f(m - M);
+        l *= f0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= f0; o1[i] *= f0; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float* pj = lds + (size_t)(j + 1) * 2 * 32 * LROW;
+            const float fj = __builtin_amdgcn_exp2f(mj[j] - M);
+            l += pj[64 + lane] * fj;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] += pj[(2 + i) * 64 + lane] * fj; o1[i] += pj[(18 + i) * 64 + lane] * fj; }
+        }
+    }
     const float inv = 1.0f / l;
     T* out = reinterpret_cast<T*>(a.CTX) + ((size_t)b * Sp + q0 + c) * a.H + hh * 64;
     if constexpr (sizeof(T) == 2) {

@@ -517,6 +517,8 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
             a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;
             // selected query tiles only: the per-wave kernel skips every other tile; a workgroup of the shared kernel would run all
             // its waves for the one tile that holds the [CLS] / class-token rows
+            static const bool ksplit_on = !(getenv("GLC_ATTN_KSPLIT") && atoi(getenv("GLC_ATTN_KSPLIT")) == 0);     // developer A/B switch
+            a.ksplit = ksplit_on ? 1 : 0;       // a workgroup with one selected query tile splits that tile's keys over its four waves
             KCHK(e->attn_impl == 3 ? launch_band(a) : glc_launch_attention(st, dt, 2, a), false);
             KCHK(glc_launch_gather_sel(st, dt, e->CTX, e->sel_b, e->sel_q, e->CTXs, R, Sp, H), false);
         } else {

@@ -115,6 +115,7 @@ struct AttnArgs {
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
     int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
     int ctx_gs = 0;                                   // workgroup-shared kernel, split operands: write CTX rows in the GS format (see below)
+    int ksplit = 0;                                   // per-wave band kernel with tile_flag: a workgroup with ONE flagged query tile splits that tile's keys over its 4 waves
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel, one independent wave per 32-query tile (attention.hip)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);

@@ -413,11 +413,18 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 if constexpr (GS && EPI == EPI_RESID) {
                     if (gsout) {
                         // raw GS row out + this 64-column block's (sum, sum of squares) of the row: the 8 lanes of a row are consecutive
+                        // (sum, M2 = sum of squared deviations from THIS block's mean): merged across blocks by Chan's formula in
+                        // ln_stats_kernel — no E[x^2] - mean^2 cancellation whatever the row's mean
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+                        for (int e = 0; e < 8; ++e) s1 += v[e];
 #pragma unroll
-                        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                        for (int o = 1; o < 8; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+                        const float bm = s1 * (1.0f / 64.0f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float dv = v[e] - bm; s2 += dv * dv; }
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) s2 += __shfl_xor(s2, o, 64);
                         if (g8 == 0) p.ln_part[(size_t)m * (N >> 6) + ((n0 + wn * 64) >> 6)] = make_float2(s1, s2);
                         vec8T oh, ol2;
 #pragma unroll

@@ -37,7 +37,7 @@ struct GemmArgs {
     // flagged tile returns at once (only the query tiles with selected rows are ever read)
     const unsigned char* q_tile_flag = nullptr;
     // LayerNorm folded into the group-split GEMMs around it (glc_launch_gemm256s_gs; DESIGN.md "LayerNorm folded away").  The producer
-    // (EPI_RESID) writes the RAW sum (GS rows, C) plus per-row partial (sum, sum of squares) of each 64-column block to ln_part
+    // (EPI_RESID) writes the RAW sum (GS rows, C) plus per-row partial (sum, squared deviations from the block mean) of each 64-column block to ln_part
     // [Mpad][N / 64]; glc_launch_ln_stats turns them into (mean, rstd) per row.  A consumer whose A rows are such raw rows gets
     // a_stats [Mpad] + ln_c [N]: W then holds W . diag(gamma), ln_c[n] = sum_k W'[n][k], bias[n] = sum_k beta[k] W[n][k] + b[n], and the
     // epilogue forms rstd_m (acc - mean_m ln_c[n]) + bias[n] = (LN(x) W^T + b)[m][n].  EPI_RESID with r_stats normalises its raw
@@ -46,7 +46,7 @@ struct GemmArgs {
     const float2* a_stats = nullptr; const float* ln_c = nullptr;
     const float2* r_stats = nullptr; const float* r_gamma = nullptr; const float* r_beta = nullptr;
 };
-// (sum, sum of squares) partials [M][nparts] -> (mean, 1 / sqrt(var + eps)) [M] over rows of H values (rows.hip; double accumulation, fixed order)
+// (sum, M2) partials of 64-column blocks [M][nparts] -> (mean, 1 / sqrt(var + eps)) [M] over rows of H = 64 nparts values (rows.hip; Chan's merge in double, fixed order)
 const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps);
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);

@@ -106,16 +106,21 @@ __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restri
     if (row >= M) return;
     ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
 }
-// LayerNorm statistics from the producer GEMM's partials (GemmArgs::ln_part)
+// LayerNorm statistics from the producer GEMM's partials (GemmArgs::ln_part: per 64-column block the sum and the squared deviations from the block mean)
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int nparts, float2* __restrict__ stats, int M, double invH, float eps) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) { const float2 v = part[(size_t)row * nparts + i]; s += (double)v.x; q += (double)v.y; }
+    // partials: (sum, M2 about the block's own mean) of each 64-column block; Chan's merge: M2 = sum M2_i + sum 64 (mean_i - mean)^2
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += (double)part[(size_t)row * nparts + i].x;
     const double mean = s * invH;
-    double var = q * invH - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    stats[row] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    double m2 = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        const float2 v = part[(size_t)row * nparts + i];
+        const double d = (double)v.x * (1.0 / 64.0) - mean;
+        m2 += (double)v.y + 64.0 * d * d;
+    }
+    stats[row] = make_float2((float)mean, (float)(1.0 / sqrt(m2 * invH + (double)eps)));
 }
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,

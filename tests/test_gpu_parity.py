@@ -131,6 +131,41 @@ def test_last_layer_pruning_is_exact(dtype, engines, weights_for):
         assert np.abs(sig(pruned) - sig(full)).max() <= tol, (B, S)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_pruned_layer_with_scattered_class_tokens(dtype, engines, weights_for):
+    """The pruned last layer computes query tiles only where [CLS] / class tokens sit: the Q third of its QKV GEMM skips 256-row tiles
+    without one, and a 4-tile workgroup of the band kernel with exactly ONE selected tile splits that tile's keys over its four waves
+    (several selected tiles: one wave per tile as before).  Class tokens are placed by hand: three tiles of the first 128-query group
+    (fallback), one tile each in two later groups (cooperative), on rows of different length; pruned == unpruned, and f32 vs the oracle."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for("mini")
+    eng = engines("mini", dtype)
+    B, S = 3, 640
+    ids, mask, _ = synth.make_inputs(cfg, B, S, 0, seed=91, ragged=True, labels_per_row=[0, 0, 0])
+    ids[ids == cfg.class_token_index] = 5
+    spots = ([1, 40, 70, 200, 300], [2, 150, 500], [300])          # class-token positions per row (row 2: one far tile only besides [CLS])
+    for b, ps in enumerate(spots):
+        n = int(mask[b].sum())
+        for q in ps:
+            if q < n - 1:
+                ids[b, q] = cfg.class_token_index
+    counts = (ids == cfg.class_token_index).sum(1)
+    assert counts.min() >= 1
+    eng.set_prune_last_layer(True)
+    pruned = eng.forward(ids, mask)
+    eng.set_prune_last_layer(False)
+    full = eng.forward(ids, mask)
+    eng.set_prune_last_layer(True)
+    C = pruned.shape[1]
+    valid = np.arange(C)[None, :] < counts[:, None]
+    tol = 1e-5 if dtype == "f32" else 5e-3
+    assert np.abs(sig(pruned) - sig(full))[valid].max() <= tol
+    if dtype == "f32":
+        ref = oracle_c.forward(cfg, w, ids, mask)
+        assert np.abs(sig(pruned) - sig(ref))[valid].max() <= TOL_PROB["f32"]
+
+
 def test_saturated_tiles_match_simple_kernel_long_sequence(engines, weights_for):
     """S = 2048: most key tiles of the band kernel take the constant-delta shortcut (|q-k| beyond the
     bucket clamp); layer output must still match the straightforward kernel."""

@@ -48,6 +48,7 @@ const char* const kProfNames[PC_N] = {"scan_rows", "embed_ln", "gemm_qkv", "atte
 struct DecLayerW {                     // decoder-style backbone (decoder.hip)
     void *Wqkv = nullptr, *Wo = nullptr, *Wgu = nullptr, *Wd = nullptr;       // T: [(nq+2nkv)d, H], [H, nq d], [2I, H] (gate rows | up rows), [H, I]
     float *bqkv = nullptr, *ln1 = nullptr, *ln2 = nullptr;                    // f32
+    void *Wqkvf = nullptr, *Wguf = nullptr;                                   // fp32 mode, RMSNorm folded into the GEMMs: Wqkv diag(ln1), Wgu diag(ln2), group-split
 };
 
 struct LayerW {
@@ -193,6 +194,11 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         }
         if (!e->fused_swiglu || e->dtype == GLC_F32) { dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
+        if (e->dtype == GLC_F32) {             // RMSNorm statistics of the two residual-stream buffers + the producers' partials
+            dfree(e, e->statsA); e->statsA = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsA) return false;
+            dfree(e, e->statsB); e->statsB = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsB) return false;
+            dfree(e, e->ln_part); e->ln_part = (float2*)dmalloc(e, (size_t)Mpad * ((c.hidden + 63) / 64) * sizeof(float2)); if (!e->ln_part) return false;
+        }
         dfree(e, e->kbias); e->kbias = (float*)dmalloc(e, (size_t)Mpad * sizeof(float)); if (!e->kbias) return false;
         e->capM = Mpad;
         e->hidden_cap = 0;
@@ -345,12 +351,22 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     }
     e->last_gs = gs;
     void *X = e->X, *Xn = e->X2;
+    // RMSNorm folded away (group-split pipeline, e->ln_fused): the residual stream is kept as RAW group-split rows plus
+    // (0, rstd) per row — statsA for the buffer X points at, statsB for the other — the projections run on weights with the RMSNorm gain
+    // folded in and scale their accumulators by rstd in the epilogue; the residual GEMMs emit the partials of the next statistics.
+    const bool rnf = gs && e->ln_fused && e->fused_swiglu && L > 0 && e->dlayers[0].Wqkvf && e->dlayers[0].Wguf && e->statsA && e->statsB && e->ln_part;
+    float2 *sX = e->statsA, *sXn = e->statsB;
+    if (rnf) {      // the embedding rows enter the pipeline: plain fp32 (X2) -> raw group-split rows (X) + statistics
+        HIPCHK(hipMemcpyAsync(e->X2, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
+        KCHK(glc_launch_rows_to_gs_rms(st, (const float*)e->X2, e->X, sX, c.ln_eps, M, H), false);
+    }
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = e->dlayers[l];
-        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln1, c.ln_eps, M, H)
+        if (!rnf) { Prof p(e, PC_LN); KCHK(gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln1, c.ln_eps, M, H)
                                     : glc_launch_rmsnorm(st, dt, X, e->H1, w.ln1, c.ln_eps, M, H), false); }                        // Q2:280
         GemmArgs g;
         g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H; g.gs_c_plain = 1;
+        if (rnf) { g.A = X; g.W = w.Wqkvf; g.a_stats = sX; }
         { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
           if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
           else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
@@ -359,12 +375,15 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
           else KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ; o.gs_resid_plain = 1;
+        if (rnf) { o.gs_resid_plain = 0; o.ln_part = e->ln_part; }        // raw group-split residual in, raw group-split sum + partials out
         { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }   // Q2:233, :291
-        std::swap(X, Xn);
-        { Prof p(e, PC_LN); KCHK(gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln2, c.ln_eps, M, H)
-                                    : glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
+        std::swap(X, Xn); std::swap(sX, sXn);
+        { Prof p(e, PC_LN); KCHK(rnf ? glc_launch_ln_stats(st, e->ln_part, H / 64, sX, M, H, c.ln_eps, 1)
+                                 : gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln2, c.ln_eps, M, H)
+                                      : glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
+        if (rnf) { f1.A = X; f1.W = w.Wguf; f1.a_stats = sX; }
         { Prof p(e, PC_FFN1);                                                                                                  // Q2:47 silu(gate) * up
           if (e->fused_swiglu && gs) { f1.C = e->FF; KCHK(glc_launch_gemm256s_gs(st, EPI_SWIGLU, f1), false); }
           else if (e->fused_swiglu && dt == GLC_F32) {      // small forward of the fp32 mode: plain rows, interleaved [gate | up] columns
@@ -374,8 +393,10 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
           else { KCHK(launch_gemm_auto(e, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I), false); } }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I; f2.gs_resid_plain = 1;
+        if (rnf) { f2.gs_resid_plain = 0; if (l + 1 < L) f2.ln_part = e->ln_part; }      // (the last layer hands plain fp32 rows to the final norm)
         { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
-        std::swap(X, Xn);
+        std::swap(X, Xn); std::swap(sX, sXn);
+        if (rnf && l + 1 < L) { Prof p(e, PC_LN); KCHK(glc_launch_ln_stats(st, e->ln_part, H / 64, sX, M, H, c.ln_eps, 1), false); }
         if (e->keep_hidden && l + 1 < L)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     }
@@ -589,7 +610,7 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
         // (fp32 mode: the group-split 256-tile GEMM has the same epilogue; its small-forward fallback un-fuses on the interleaved columns)
         e->fused_swiglu = (e->dtype != GLC_F32 || (e->w_presplit && e->dec_split && H % 256 == 0)) && (2 * I) % 256 == 0 && H % 32 == 0 && I % 16 == 0 &&
                           glc_gemm_use_stagger() && getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
-        std::vector<float> bqkv(NQKV), gu_host(e->fused_swiglu ? 2 * (size_t)I * H : 0);
+        std::vector<float> bqkv(NQKV), gu_host(e->fused_swiglu ? 2 * (size_t)I * H : 0), fold_host;
         bool lok = true;
         for (int l = 0; l < L && lok; ++l) {
             const float* const* t = tensors + 1 + GLC_DEC_TENSORS_PER_LAYER * l;    // ln1 qw qb kw kb vw vb ow ln2 gw uw dw
@@ -618,6 +639,24 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
                 if (!pm) pm = glc_launch_presplit(e->stream, w.Wo, (size_t)H * NQ);
                 if (!pm) pm = glc_launch_presplit(e->stream, w.Wgu, 2 * (size_t)I * H);
                 if (!pm) pm = glc_launch_presplit(e->stream, w.Wd, (size_t)H * I);
+                if (pm) { set_err(pm); lok = false; break; }
+            }
+            if (e->ln_fused && e->w_presplit && e->dtype == GLC_F32 && e->fused_swiglu && H % 64 == 0) {
+                // RMSNorm folded into the consumer GEMMs of the group-split pipeline: RMSNorm(x) W^T = rstd (x (W diag(gamma))^T)
+                auto fold_rows = [&](const float* Wsrc, size_t rows, const float* gam, float* dst) {
+                    for (size_t n = 0; n < rows; ++n) for (int k = 0; k < H; ++k) dst[n * H + k] = Wsrc[n * H + k] * gam[k];
+                };
+                std::vector<float>& wf = fold_host;
+                wf.resize(2 * (size_t)I * H > NQKV * H ? 2 * (size_t)I * H : NQKV * H);
+                fold_rows(t[1], NQ, t[0], wf.data()); fold_rows(t[3], NKV, t[0], wf.data() + NQ * H); fold_rows(t[5], NKV, t[0], wf.data() + (NQ + NKV) * H);
+                w.Wqkvf = dmalloc(e, NQKV * H * es, false);
+                if (!w.Wqkvf || !upload_as(e, wf.data(), NQKV * H, w.Wqkvf, staging)) { lok = false; break; }
+                const char* pm = glc_launch_presplit(e->stream, w.Wqkvf, NQKV * H);
+                if (pm) { set_err(pm); lok = false; break; }
+                fold_rows(gu_host.data(), 2 * (size_t)I, t[8], wf.data());           // the interleaved [16 gate | 16 up] row order is kept
+                w.Wguf = dmalloc(e, 2 * (size_t)I * H * es, false);
+                if (!w.Wguf || !upload_as(e, wf.data(), 2 * (size_t)I * H, w.Wguf, staging)) { lok = false; break; }
+                pm = glc_launch_presplit(e->stream, w.Wguf, 2 * (size_t)I * H);
                 if (pm) { set_err(pm); lok = false; break; }
             }
             for (size_t i = 0; i < NQ; ++i) bqkv[i] = t[2][i];

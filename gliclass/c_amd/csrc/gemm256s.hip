@@ -237,19 +237,24 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         // exchange.  The wave's 128x64 sub-tile becomes 128x32 outputs (Q2:47 silu(gate(x)) * up(x)); patch [32 rows][32
         // features], row stride 36 floats; 16-byte stores of 8 features.
         const int I = N >> 1;
+        // RMSNorm folded into this GEMM (GemmArgs::a_stats: W holds W diag(gamma), the rows are raw): gate and up scale by the row's rstd
+        const bool lnf = GS && p.a_stats != nullptr;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int ii = 0; ii < 2; ++ii) {
+                const float rs = lnf ? p.a_stats[m0 + wm * 128 + (2 * c + ii) * 16 + r16].y : 1.0f;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const f32x4 gt = acc[2 * c + ii][2 * jj], up = acc[2 * c + ii][2 * jj + 1];
+                    f32x4 gt = acc[2 * c + ii][2 * jj], up = acc[2 * c + ii][2 * jj + 1];
+                    if (lnf) { gt *= rs; up *= rs; }
                     f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         v[r] = gt[r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt[r])) * up[r];
                     *reinterpret_cast<f32x4*>(stg + (ii * 16 + r16) * 36 + jj * 16 + 4 * g) = v;
                 }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -292,7 +297,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         if constexpr (GS && EPI != EPI_RESID) {
             if (lnf) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const f32x4 cv = *reinterpret_cast<const f32x4*>(p.ln_c + n0 + wn * 64 + j * 16 + 4 * g); cj[j][0] = cv[0]; cj[j][1] = cv[1]; cj[j][2] = cv[2]; cj[j][3] = cv[3]; }
+                for (int j = 0; j < 4; ++j) {       // (RMSNorm: no mean, no ln_c)
+                    const f32x4 cv = p.ln_c ? *reinterpret_cast<const f32x4*>(p.ln_c + n0 + wn * 64 + j * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    cj[j][0] = cv[0]; cj[j][1] = cv[1]; cj[j][2] = cv[2]; cj[j][3] = cv[3];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) st_i[i] = p.a_stats[m0 + wm * 128 + i * 16 + r16];
             }
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         const bool lnf = GS && p.a_stats != nullptr;       // LayerNorm folded into this GEMM (GemmArgs::a_stats)
         if (lnf) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cn[j] = p.ln_c[n0 + wn * 64 + j * 16 + r16];
+            for (int j = 0; j < 4; ++j) cn[j] = p.ln_c ? p.ln_c[n0 + wn * 64 + j * 16 + r16] : 0.f;
         }
         const int hh = (n0 + wn * 64 - 2 * p.H) >> 6;
 #pragma unroll

@@ -47,7 +47,9 @@ struct GemmArgs {
     const float2* r_stats = nullptr; const float* r_gamma = nullptr; const float* r_beta = nullptr;
 };
 // (sum, M2) partials of 64-column blocks [M][nparts] -> (mean, 1 / sqrt(var + eps)) [M] over rows of H = 64 nparts values (rows.hip; Chan's merge in double, fixed order)
-const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps);
+const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps, int rms = 0);   // rms: (0, 1 / sqrt(E[x^2] + eps))
+// decoder backbone: plain fp32 rows -> raw group-split rows + RMSNorm statistics (0, rstd) per row
+const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H);
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);
 const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a);    // 256x256 tile, 16-bit T

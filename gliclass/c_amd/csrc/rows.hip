@@ -106,8 +106,26 @@ __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restri
     if (row >= M) return;
     ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
 }
+// decoder backbone, RMSNorm folded into the GEMMs: the embedding rows (plain fp32) enter the pipeline as raw group-split rows + (0, rstd)
+__global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63, nch = H / 8;
+    const float* x = X + (size_t)row * H;
+    f16_t* y = Y + (size_t)row * 2 * H;
+    float ss = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8), b = *reinterpret_cast<const f32x4*>(x + (size_t)ch * 8 + 4);
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+        gs_store8(y, ch * 8, v);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) stats[row] = make_float2(0.f, rsqrtf(ss / (float)H + eps));
+}
 // LayerNorm statistics from the producer GEMM's partials (GemmArgs::ln_part: per 64-column block the sum and the squared deviations from the block mean)
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int nparts, float2* __restrict__ stats, int M, double invH, float eps) {
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int nparts, float2* __restrict__ stats, int M, double invH, float eps, int rms) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
     // partials: (sum, M2 about the block's own mean) of each 64-column block; Chan's merge: M2 = sum M2_i + sum 64 (mean_i - mean)^2
@@ -120,7 +138,9 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict_
         const double d = (double)v.x * (1.0 / 64.0) - mean;
         m2 += (double)v.y + 64.0 * d * d;
     }
-    stats[row] = make_float2((float)mean, (float)(1.0 / sqrt(m2 * invH + (double)eps)));
+    // rms: RMSNorm statistics (0, 1 / sqrt(E[x^2] + eps)), E[x^2] = var + mean^2
+    if (rms) stats[row] = make_float2(0.f, (float)(1.0 / sqrt(m2 * invH + mean * mean + (double)eps)));
+    else stats[row] = make_float2((float)mean, (float)(1.0 / sqrt(m2 * invH + (double)eps)));
 }
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,
@@ -397,9 +417,15 @@ const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, con
     return nullptr;
 }
 
-const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps) {
-    if (!part || !stats || M <= 0 || H <= 0 || nparts <= 0 || nparts > 1024) return "ln_stats: bad args";
-    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, nparts, stats, M, 1.0 / (double)H, eps);
+const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps, int rms) {
+    if (!part || !stats || M <= 0 || H <= 0 || nparts <= 0 || nparts > 1024 || nparts * 64 != H) return "ln_stats: bad args";
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, nparts, stats, M, 1.0 / (double)H, eps, rms);
+    return nullptr;
+}
+
+const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H) {
+    if (!X || !Y || !stats || M <= 0 || H <= 0 || H % 32) return "rows_to_gs_rms: bad args";
+    hipLaunchKernelGGL(rows_to_gs_rms_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H);
     return nullptr;
 }
 

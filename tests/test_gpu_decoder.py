@@ -243,5 +243,15 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
             assert np.isfinite(gs).all()
             assert np.abs(sig(gs) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
             assert np.abs(sig(gs) - sig(plain)).max() <= 1e-4, (B, S)
+            # RMSNorm folded into the GEMMs (default: raw group-split residual stream + (0, rstd) per row, gain folded into the
+            # weights, rstd applied in the QKV / SwiGLU epilogues) against RMSNorm as kernels of its own
+            eng.set_ln_fused(False)
+            unf = eng.forward(ids, mask)
+            eng.set_ln_fused(True)
+            assert eng.last_group_split()
+            assert np.abs(sig(unf) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
+            assert np.abs(sig(gs) - sig(unf)).max() <= 1e-4, (B, S)
+            if cfg.hidden % 256 == 0:
+                assert not np.array_equal(gs, unf), "the RMSNorm switch changed nothing: is the folded path running?"
     finally:
         eng.close()

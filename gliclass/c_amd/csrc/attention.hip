@@ -576,11 +576,16 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
         static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: lean two-step band loop; the env picks the rolled one (A/B)
         if (dtype == GLC_DT_F32) {
             if (a.stamps) return "attention: the stamped build exists for f16 only";
-            // The lean (in-place reload) loop is not built for split fragments: round 1 measured it 5 % faster but WRONG (err 5e-2) while the
-            // same source is correct with plain fp32 and 16-bit fragments; not root-caused, so the combination does not exist.  The split
-            // mode's attention is attention_wg.hip; this kernel serves it only for the pruned last layer, in the rolled form.
+            // The lean (in-place reload) loop with split fragments: round 1 measured it 5 % faster but WRONG (err 5e-2).  Root cause (round 2,
+            // DESIGN.md section 2): a wait count that hipcc leaves out in THIS instantiation once its SLP vectoriser has formed packed-fp32
+            // (v_pk_*_f32) instructions — the same object is correct with -mllvm -amdgpu-waitcnt-forcezero, with packed fp32 disabled, or
+            // with -fno-slp-vectorize, which is how this translation unit is built (Makefile); in that build the instantiation passes the
+            // whole fp32 parity suite (GLC_ATTN_WG=0 GLC_ATTN_SPLIT_LEAN=1).  It stays a diagnostic: the split mode's attention is
+            // attention_wg.hip, and this kernel serves it only for the pruned last layer, in the rolled form.
             static const bool lean32 = getenv("GLC_ATTN_F32_LEAN") != nullptr;      // diagnostic only: plain fp32 fragments, lean loop
-            if (a.split) hipLaunchKernelGGL((attn_band_kernel<float, false, false, true>), grid, block, dyn, st, a);
+            static const bool split_lean = getenv("GLC_ATTN_SPLIT_LEAN") != nullptr;     // diagnostic only: split fragments, lean loop
+            if (a.split && split_lean) hipLaunchKernelGGL((attn_band_kernel<float, true, false, true>), grid, block, dyn, st, a);
+            else if (a.split) hipLaunchKernelGGL((attn_band_kernel<float, false, false, true>), grid, block, dyn, st, a);
             else if (lean32) hipLaunchKernelGGL((attn_band_kernel<float, true>), grid, block, dyn, st, a);
             else hipLaunchKernelGGL((attn_band_kernel<float, false>), grid, block, dyn, st, a);
         } else if (a.stamps) {

@@ -302,7 +302,10 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
                 flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
                 mfma_per_product=mpp, executed_mfma_frac=round(per[dom]["tflops"] * mpp / peak, 4),
                 e2e_achieved=round(e2e, 1), e2e_peak=peak, e2e_frac=round(e2e / peak, 4),
-                executed_flops_frac=round(executed / peak, 4), per_kernel=per)
+                executed_flops_frac=round(executed / peak, 4),
+                # MFMA utilisation of the whole forward: FLOPs the matrix pipes really execute (every product of this mode costs
+                # mfma_per_product MFMAs; the pruned last layer counted at its real size) over the dense f16 / bf16 MFMA peak
+                mfma_utilisation=round(executed * mpp / peak, 4), per_kernel=per)
 
 
 def prob_err(a, b):

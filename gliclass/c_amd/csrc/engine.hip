@@ -75,6 +75,7 @@ struct glc_engine {
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
     bool last_gs = false;           // the last forward ran the group-split pipeline
     bool ln_fused = true;           // group-split pipeline: LayerNorm folded into the GEMMs around it (GLC_LNF=0: separate LayerNorm kernels)
+    bool last_lnf = false;          // the last forward ran with LayerNorm / RMSNorm folded into its GEMMs
     float2 *statsA = nullptr, *statsB = nullptr, *ln_part = nullptr;     // (mean, rstd) per row of X / H1 when they hold raw sums; the producers' partials
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
@@ -207,7 +208,7 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         void** bufs[] = {&e->X, &e->Qh, &e->Kh, &e->Vt, &e->CTX, &e->T1, &e->H1};
         for (void** b : bufs) { dfree(e, *b); *b = dmalloc(e, (size_t)Mpad * c.hidden * es); if (!*b) return false; }
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
-        if (e->dtype == GLC_F32) {             // (small; kept whether or not the fold is switched on: glc_debug_set_ln_fused)
+        {                                      // (small; kept whether or not the fold is switched on: glc_debug_set_ln_fused)
             dfree(e, e->statsA); e->statsA = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsA) return false;
             dfree(e, e->statsB); e->statsB = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsB) return false;
             dfree(e, e->ln_part); e->ln_part = (float2*)dmalloc(e, (size_t)Mpad * ((c.hidden + 63) / 64) * sizeof(float2)); if (!e->ln_part) return false;
@@ -356,6 +357,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     // folded in and scale their accumulators by rstd in the epilogue; the residual GEMMs emit the partials of the next statistics.
     const bool rnf = gs && e->ln_fused && e->fused_swiglu && L > 0 && e->dlayers[0].Wqkvf && e->dlayers[0].Wguf && e->statsA && e->statsB && e->ln_part;
     float2 *sX = e->statsA, *sXn = e->statsB;
+    e->last_lnf = rnf;
     if (rnf) {      // the embedding rows enter the pipeline: plain fp32 (X2) -> raw group-split rows (X) + statistics
         HIPCHK(hipMemcpyAsync(e->X2, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
         KCHK(glc_launch_rows_to_gs_rms(st, (const float*)e->X2, e->X, sX, c.ln_eps, M, H), false);
@@ -463,6 +465,12 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         gs = e->gs_mode == 2 || !glc_gemm_small_m(t);
     }
     e->last_gs = gs;
+    // 16-bit modes: the same LayerNorm fold on plain rows of T, when all four projections of a layer run on the staggered 256-tile kernel
+    bool fold16 = false;
+    if (dt != GLC_F32 && e->ln_fused && prune && !e->keep_hidden && e->attn_impl != 1 && H % 256 == 0 && I % 256 == 0 && glc_gemm_use_stagger() && e->statsA && e->statsB && e->ln_part) {
+        GemmArgs t; t.Mpad = Mpad; t.N = H; t.K = H;
+        fold16 = glc_gemm256_supported(dt, t) && !glc_gemm_small_m(t);
+    }
     { Prof p(e, PC_EMBED);
       if (gs) KCHK(glc_launch_embed_gs(st, ids, mask, (const float*)e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false);
       else KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
@@ -475,7 +483,8 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         // LayerNorm folded away (group-split pipeline, e->ln_fused): X / H1 then hold the RAW residual sums of the producer GEMMs plus
         // (mean, rstd) per row in statsA / statsB; the consumers run on weights with gamma folded in.  Normalised rows stay where a
         // kernel outside the pipeline reads them: the embedding output (layer 0) and the input of the pruned last layer.
-        const bool lnf = gs && e->ln_fused && w.W1f && (l == 0 || w.Wqkvf);
+        const bool lnf = (gs || fold16) && e->ln_fused && w.W1f && (l == 0 || w.Wqkvf);
+        if (l == 0) e->last_lnf = lnf;
         const bool x_raw = x_is_raw;         // X holds raw sums + statsA (written by the previous layer's FFN2)
         GemmArgs g;
         g.A = e->X; g.W = w.Wqkv; g.bias = w.bqkv; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt;
@@ -841,7 +850,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 gm = glc_launch_gemm_auto(e->stream, dtype, EPI_QKV, g);
                 if (gm) { set_err(gm); lok = false; }
             }
-            if (lok && e->ln_fused && e->w_presplit && dtype == GLC_F32) {
+            if (lok && e->ln_fused && ((e->w_presplit && dtype == GLC_F32) || dtype != GLC_F32)) {
                 // LayerNorm folded into the consumer GEMMs of the group-split pipeline (GemmArgs::a_stats):
                 //   W1' = W1 diag(gamma1), c1 = W1' 1, d1 = W1 beta1 + b1            (this layer's ln1 feeds its FFN1)
                 //   Wqkv' = Wqkv diag(gamma2 of layer l - 1), cq, dq likewise          (the previous layer's ln2 feeds this QKV; layer 0
@@ -859,7 +868,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 fold(t[10], I, t[8], t[9], t[11], 0);
                 w.W1f = dmalloc(e, (size_t)I * H * es, false);
                 if (!w.W1f || !upload_as(e, wf.data(), (size_t)I * H, w.W1f, staging)) { lok = false; break; }
-                const char* pm = glc_launch_presplit(e->stream, w.W1f, (size_t)I * H);
+                const char* pm = dtype == GLC_F32 ? glc_launch_presplit(e->stream, w.W1f, (size_t)I * H) : nullptr;     // (16-bit modes: plain rows of T)
                 if (pm) { set_err(pm); lok = false; break; }
                 w.c1 = upload_f32(e, cv.data(), I); w.d1 = upload_f32(e, dv.data(), I);
                 if (!w.c1 || !w.d1) { lok = false; break; }
@@ -870,7 +879,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                     fold(t[4], H, tp[14], tp[15], bqkv.data(), 2 * H);
                     w.Wqkvf = dmalloc(e, 3 * (size_t)H * H * es, false);
                     if (!w.Wqkvf || !upload_as(e, wf.data(), 3 * (size_t)H * H, w.Wqkvf, staging)) { lok = false; break; }
-                    pm = glc_launch_presplit(e->stream, w.Wqkvf, 3 * (size_t)H * H);
+                    pm = dtype == GLC_F32 ? glc_launch_presplit(e->stream, w.Wqkvf, 3 * (size_t)H * H) : nullptr;
                     if (pm) { set_err(pm); lok = false; break; }
                     w.cq = upload_f32(e, cv.data(), 3 * (size_t)H); w.dq = upload_f32(e, dv.data(), 3 * (size_t)H);
                     if (!w.cq || !w.dq) { lok = false; break; }
@@ -1140,6 +1149,7 @@ int glc_debug_set_group_split(glc_engine* e, int mode) {
 int glc_debug_last_forward_group_split(const glc_engine* e) { return e ? (e->last_gs ? 1 : 0) : -1; }
 /* Group-split pipeline with LayerNorm folded into the GEMMs (1, default) or as kernels of its own (0).  The folded weights are built
  * at load unless GLC_LNF=0 was set then; without them the switch has no effect. */
+int glc_debug_last_forward_ln_folded(const glc_engine* e) { return e ? (e->last_lnf ? 1 : 0) : -1; }
 int glc_debug_set_ln_fused(glc_engine* e, int on) {
     if (!e) return -1;
     std::lock_guard<std::mutex> lk(e->mu);

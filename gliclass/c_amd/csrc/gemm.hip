@@ -322,6 +322,7 @@ template <typename T, bool SPLIT = false> void launch_t(hipStream_t st, int epi,
 //   K % (128 / sizeof(T)) == 0; for EPI_QKV additionally H % 128 == 0, Sp % 64 == 0 (fragment-major
 //   Q/K/V^T outputs, glc_layout.h).
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
+    if (a.a_stats || a.r_stats || a.ln_part) return "gemm: the LayerNorm-fold arguments exist for the staggered 256-tile kernel only";
     const int esz = dtype == GLC_DT_F32 ? 4 : 2;
     if (a.Mpad <= 0 || a.Mpad % BM) return "gemm: Mpad must be a positive multiple of 128";
     if (a.N <= 0 || a.N % BN) return "gemm: N must be a multiple of 128";

@@ -308,6 +308,7 @@ bool glc_gemm256_supported(int dtype, const GemmArgs& a) {
 // Host-side shape contract: 16-bit T; Mpad % 256 == 0 (buffers allocated with Mpad rows), N % 256 == 0,
 // K % 64 == 0; EPI_QKV: H % 256 == 0 (a tile never straddles Q|K|V), Sp % 64 == 0.
 const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a_in) {
+    if (a_in.a_stats || a_in.r_stats || a_in.ln_part) return "gemm: the LayerNorm-fold arguments exist for the staggered 256-tile kernel only";
     GemmArgs a = a_in;
     static const int env_spread = getenv("GLC_GEMM_SPREAD") ? atoi(getenv("GLC_GEMM_SPREAD")) : 1;   // default on (A/B switch)
     a.spread_dma = env_spread;

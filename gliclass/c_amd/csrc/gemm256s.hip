@@ -291,10 +291,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         }
         // LayerNorm folded into this GEMM (GemmArgs::a_stats): the accumulator is raw_row . (W diag(gamma))^T; the lane's 8 accumulator
         // rows are m0 + 128 wm + 16 i + r16
-        const bool lnf = GS && EPI != EPI_RESID && p.a_stats != nullptr;
-        float cj[GS ? 4 : 1][4];
-        float2 st_i[GS ? 8 : 1];
-        if constexpr (GS && EPI != EPI_RESID) {
+        const bool lnf = EPI != EPI_RESID && p.a_stats != nullptr;
+        float cj[4][4];
+        float2 st_i[8];
+        if constexpr (EPI != EPI_RESID) {
             if (lnf) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {       // (RMSNorm: no mean, no ln_c)
@@ -306,29 +306,29 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
             }
         }
         // EPI_RESID with GemmArgs::r_stats: the residual rows are raw, LayerNorm is applied on the fly; this lane's 8 columns
-        float rg[GS ? 8 : 1], rb[GS ? 8 : 1];
-        const bool rln = GS && EPI == EPI_RESID && p.r_stats != nullptr;
-        const bool gsout = GS && EPI == EPI_RESID && p.ln_part != nullptr;     // raw GS rows + statistics partials out (non-wide lane map)
-        if constexpr (GS && EPI == EPI_RESID) {
+        float rg[8], rb[8];
+        const bool rln = EPI == EPI_RESID && p.r_stats != nullptr;
+        const bool gsout = EPI == EPI_RESID && p.ln_part != nullptr;     // raw rows (group-split, or T in the 16-bit modes) + statistics partials out; lane map: 8 consecutive columns
+        if constexpr (EPI == EPI_RESID) {
             if (rln) {
-                const int nb = n0 + wn * 64 + (gsout ? (lane & 7) * 8 : (lane & 7) * 4);
+                const int nb = n0 + wn * 64 + ((gsout || !GS) ? (lane & 7) * 8 : (lane & 7) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     rg[e] = p.r_gamma[nb + e]; rb[e] = p.r_beta[nb + e];
-                    rg[4 + e] = p.r_gamma[nb + (gsout ? 4 : 32) + e]; rb[4 + e] = p.r_beta[nb + (gsout ? 4 : 32) + e];
+                    rg[4 + e] = p.r_gamma[nb + ((gsout || !GS) ? 4 : 32) + e]; rb[4 + e] = p.r_beta[nb + ((gsout || !GS) ? 4 : 32) + e];
                 }
             }
         }
         // residual rows are fetched one 32-row chunk AHEAD of their use (16-byte coalesced loads): without this each
         // chunk exposed a full HBM round trip between its LDS read-back and its store (+4.7 us per tile measured)
         vec8T rpre[4], rpre_lo[GS ? 4 : 1];
-        float2 rst_pre[GS ? 4 : 1];
-        auto load_resid = [&](int c, vec8T (&r)[4], vec8T (&rl)[GS ? 4 : 1], float2 (&rst)[GS ? 4 : 1]) {
+        float2 rst_pre[4];
+        auto load_resid = [&](int c, vec8T (&r)[4], vec8T (&rl)[GS ? 4 : 1], float2 (&rst)[4]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
+                if (rln) rst[k] = p.r_stats[m0 + wm * 128 + c * 32 + row];
                 if constexpr (GS) {
-                    if (rln) rst[k] = p.r_stats[m0 + wm * 128 + c * 32 + row];
                     if (gsout) {                 // 8 consecutive columns per lane (GS residual rows only: the fused pipeline never mixes in plain ones)
                         const int n = n0 + wn * 64 + g8 * 8;
                         const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
@@ -361,10 +361,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             vec8T rcur[4], rcur_lo[GS ? 4 : 1];
-            float2 rst_cur[GS ? 4 : 1];
+            float2 rst_cur[4];
             if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { rcur[k] = rpre[k]; if constexpr (GS) { rcur_lo[k] = rpre_lo[k]; rst_cur[k] = rst_pre[k]; } }
+                for (int k = 0; k < 4; ++k) { rcur[k] = rpre[k]; rst_cur[k] = rst_pre[k]; if constexpr (GS) rcur_lo[k] = rpre_lo[k]; }
                 if (c + 1 < 4) load_resid(c + 1, rpre, rpre_lo, rst_pre);
             }
 #pragma unroll
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = acc[2 * c + ii][j];
-                    if constexpr (GS && EPI != EPI_RESID) {
+                    if constexpr (EPI != EPI_RESID) {
                         if (lnf) {
                             const float2 sm = st_i[2 * c + ii];
 #pragma unroll
@@ -406,19 +406,19 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                         const f32x4 ra = __builtin_bit_cast(f32x4, rcur[k]), rb4 = __builtin_bit_cast(f32x4, rcur_lo[GS ? k : 0]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += ra[e]; v[4 + e] += rb4[e]; }
-                    } else if (GS && rln) {     // raw residual row: LayerNorm on the fly
-                        const float2 sm = rst_cur[GS ? k : 0];
+                    } else if (rln) {           // raw residual row: LayerNorm on the fly
+                        const float2 sm = rst_cur[k];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float r = (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e];
-                            v[e] += (r - sm.x) * sm.y * rg[GS ? e : 0] + rb[GS ? e : 0];
+                            const float r = GS ? (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e] : (float)rcur[k][e];
+                            v[e] += (r - sm.x) * sm.y * rg[e] + rb[e];
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += GS ? (float)rcur[k][e] + (float)rcur_lo[GS ? k : 0][e] : (float)rcur[k][e];
                     }
                 }
-                if constexpr (GS && EPI == EPI_RESID) {
+                if constexpr (EPI == EPI_RESID) {
                     if (gsout) {
                         // raw GS row out + this 64-column block's (sum, sum of squares) of the row: the 8 lanes of a row are consecutive
                         // (sum, M2 = sum of squared deviations from THIS block's mean): merged across blocks by Chan's formula in
@@ -437,9 +437,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                         vec8T oh, ol2;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { oh[e] = (T)v[e]; ol2[e] = (T)(v[e] - (float)oh[e]); }
-                        T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * N + (n >> 5) * 64 + (n & 31);
-                        *reinterpret_cast<vec8T*>(cp) = oh;
-                        *reinterpret_cast<vec8T*>(cp + 32) = ol2;
+                        if constexpr (GS) {
+                            T* cp = reinterpret_cast<T*>(p.C) + (size_t)m * 2 * N + (n >> 5) * 64 + (n & 31);
+                            *reinterpret_cast<vec8T*>(cp) = oh;
+                            *reinterpret_cast<vec8T*>(cp + 32) = ol2;
+                        } else *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.C) + (size_t)m * N + n) = oh;      // 16-bit modes: the raw row in T
                         continue;
                     }
                 }
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         float bn[4], cn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) bn[j] = bias ? bias[n0 + wn * 64 + j * 16 + r16] : 0.f;
-        const bool lnf = GS && p.a_stats != nullptr;       // LayerNorm folded into this GEMM (GemmArgs::a_stats)
+        const bool lnf = p.a_stats != nullptr;             // LayerNorm folded into this GEMM (GemmArgs::a_stats)
         if (lnf) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) cn[j] = p.ln_c ? p.ln_c[n0 + wn * 64 + j * 16 + r16] : 0.f;

@@ -103,6 +103,9 @@ class Engine:
     def last_group_split(self):
         return bool(self.L.glc_debug_last_forward_group_split(self.h))
 
+    def last_ln_folded(self):
+        return bool(self.L.glc_debug_last_forward_ln_folded(self.h))
+
     def set_ln_fused(self, on):
         """group-split pipeline: LayerNorm folded into the GEMMs around it (default) or as kernels of its own"""
         if self.L.glc_debug_set_ln_fused(self.h, int(bool(on))) != 0:

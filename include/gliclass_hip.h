@@ -137,6 +137,7 @@ int glc_debug_last_forward_group_split(const glc_engine* e);
 /* Group-split pipeline: LayerNorm folded into the GEMMs around it (1, default: the producer writes raw rows + row statistics, the consumer
  * runs on weights with gamma folded in and finishes (LN(x) W^T + b) in its epilogue) or as kernels of its own (0). */
 int glc_debug_set_ln_fused(glc_engine* e, int on);
+int glc_debug_last_forward_ln_folded(const glc_engine* e);      /* 1: the last forward ran with the norm folded into its GEMMs (every mode) */
 
 /* clamp(bucket(q-k)+span, 0, 2span-1) for q-k in [-(S-1), S-1] at out[q-k+S-1] (float32 math as
  * torch).  Pure host function (no GPU needed). */

@@ -574,6 +574,36 @@ def test_second_device_gives_identical_results(weights_for):
             e0.close(); e1.close()
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_layernorm_fold_16bit_modes(dtype, engines, weights_for):
+    """16-bit modes, forwards large enough for the staggered 256-tile GEMM: LayerNorm folded into the GEMMs around it (raw rows of T +
+    row statistics out of the residual GEMMs, gamma-folded weights + epilogue correction in QKV / FFN1) against LayerNorm as kernels of
+    its own — same function, other rounding points — and a few rows against the oracle."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    cfg, w = weights_for("small")
+    eng = engines("small", dtype)
+    B, S = 40, 512
+    ids, mask, _ = synth.make_inputs(cfg, B, S, 4, seed=123, ragged=True)
+    eng.set_length_buckets(1)
+    try:
+        fused = eng.forward(ids, mask)
+        assert eng.last_ln_folded(), "this shape should run the folded pipeline"
+        eng.set_ln_fused(False)
+        unf = eng.forward(ids, mask)
+        assert not eng.last_ln_folded()
+    finally:
+        eng.set_ln_fused(True)
+        eng.set_length_buckets(4)
+    assert np.isfinite(fused).all() and not np.array_equal(fused, unf)
+    tol = TOL_PROB[dtype]
+    assert np.abs(sig(fused) - sig(unf)).max() <= tol
+    for b in (0, 7, 33):
+        n = int(mask[b].sum())
+        ref = oracle_c.forward(cfg, w, ids[b:b + 1, :n], mask[b:b + 1, :n])
+        assert np.abs(sig(fused[b:b + 1, :ref.shape[1]]) - sig(ref)).max() <= tol, b
+
+
 @pytest.mark.parametrize("cname", ["mini", "small"])
 def test_group_split_pipeline_vs_oracle_and_plain_fp32(cname, engines, weights_for):
     """fp32 mode, the two activation formats: plain fp32 rows + 128-tile split-f16 GEMMs (small forwards) and group-split rows

@@ -7,6 +7,7 @@
 
 #include <fcntl.h>
 #include <math.h>
+#include "glc_cpus.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,7 +26,9 @@ uint64_t glc_fnv1a64(const char* s) {
 
 void glc_prng_fill(uint64_t seed, const char* name, size_t n, double amp, double mean, float* out) {
     const uint64_t base = glc_fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15ull);
-#pragma omp parallel for schedule(static)
+    /* team sized to the CPUs this process may really use (affinity + cgroup quota): the OpenMP default — every core of the host —
+     * took 25 s for the base model on a 16-CPU share of a large box (oversubscribed spin-waiting teams), 0.2 s with the clamp */
+#pragma omp parallel for schedule(static) num_threads(glc_host_cpus()) if (n > 65536)
     for (size_t i = 0; i < n; ++i) {
         uint64_t z = base + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -74,8 +74,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
 // VGL (split units, NW = 4): only K goes through the ring (8 KiB per tile = two DMA pieces per wave); V^T fragments are loaded per wave
 // from global memory.  80 KiB of LDS: TWO workgroups of four waves per CU, i.e. the two waves of a SIMD belong to different workgroups.
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them).
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false>
+// PD (split units): precision-budget build — AttnArgs::prec rounds operand tensors to f16 at run time by zeroing their lo halves
+// (bits: 1 Q, 2 K, 4 V^T, 8 P, 16 PQ rows, 32 PK rows); numerically the kernel that never fetches / forms them, at unchanged cost.
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false, bool PD = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
+    static_assert(!PD || SPLIT, "precision switches act on split units");
     static_assert(!STAG || (NW == 8 && !KVG), "the stagger pairs the two 4-wave halves of an 8-wave workgroup");
     static_assert(!VGL || (SPLIT && NW == 4 && !KVG && !STAG), "V^T from global: the 4-wave split-unit variant");
     static_assert(!SPLIT || sizeof(T) == 4, "split operands live in the fp32 layouts");
@@ -157,9 +160,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
         const int r = (x >> SH) & 31;
         return x + ((glc_pi32(r) - r) << SH);
     };
+    auto drop_lo = [&](frag_t& f, int bit) __attribute__((always_inline)) {
+        if constexpr (PD) { if (a.prec & bit) f.lo = (f16x8)(f16_t)0; }
+    };
     auto load_rows = [&](const unsigned char* base, int off, frag_t (&f)[4]) {       // 4 fragment units of gathered table rows
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const frag_t*>(base + off + s * UNITB);
+        for (int s = 0; s < 4; ++s) { f[s] = *reinterpret_cast<const frag_t*>(base + off + s * UNITB); drop_lo(f[s], base == PQg ? 16 : 32); }
     };
     // One fragment unit out of the ring.  16-bit operands: the unit is the linear copy of its 1 KiB in HBM (16 B per lane).  Split units
     // (32 B per lane in HBM: [8 hi | 8 lo]) are re-arranged by the DMA into [64 lanes x hi | 64 lanes x lo]: read lane-strided at 32 B
@@ -181,6 +187,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) f[s] = ring_unit(tile + s * UNITB);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) drop_lo(f[s], 2);
     };
     auto band_store = [&](float* dst, const f32x16& v) {           // 4 consecutive rr per register group
 #pragma unroll
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 
     frag_t qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const frag_t*>(Qg + s * UNITB);
+    for (int s = 0; s < 4; ++s) { qf[s] = *reinterpret_cast<const frag_t*>(Qg + s * UNITB); drop_lo(qf[s], 1); }
     dma_tile(0);
     if (nkt > 1) dma_tile(1);
     frag_t kf[4];                           // KVG: always holds K(kt) at the top of tile kt (re-loaded in place after its last MFMA)
@@ -246,6 +254,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
                 vt[1][t] = ring_unit(vtile + (2 + t) * UNITB);
             }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { drop_lo(vt[0][t], 4); drop_lo(vt[1][t], 4); }
         if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
                     pfr.hi[j] = ph;
                     pfr.lo[j] = (f16_t)(sv[8 * t + j] - (float)ph);
                 }
+                drop_lo(pfr, 8);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
@@ -306,6 +317,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
         for (int s = 0; s < 4; ++s) {       // broadcast fragments: every row / column is table row d*
             pqb[s] = *reinterpret_cast<const frag_t*>(PQg + ((size_t)(dstar >> 5) * 2048 + (dstar & 31) * 8) * sizeof(T) + s * UNITB);
             pkb[s] = *reinterpret_cast<const frag_t*>(PKg + ((size_t)(dstar >> 5) * 2048 + glc_pi32(dstar & 31) * 8) * sizeof(T) + s * UNITB);
+            drop_lo(pqb[s], 16); drop_lo(pkb[s], 32);
         }
         float cq;
         {
@@ -529,19 +541,19 @@ template <typename T, bool SPLIT, int NW, bool KVG, bool STAG, bool VGL> constex
                 : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false, bool PD = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> raised{0};
     constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG, VGL>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
     static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG>, 64 * NW, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD>, 64 * NW, lds);
         fprintf(stderr, "[attn_wg] NW=%d lds=%zu bytes, occupancy API: %d workgroup(s) per CU\n", NW, lds, nb);
     }
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
     return nullptr;
 }
 
@@ -556,6 +568,7 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
     if (dtype == GLC_DT_F32) {
         if (!a.split) return "attention(wg): the fp32 mode runs this kernel on split-f16 units only";
         if (a.stamps) return launch_wg<float, true, 8, false, false, false, true>(st, a);
+        if (a.prec) return launch_wg<float, true, 8, false, false, false, false, true>(st, a);      // precision-budget build
         // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
         static const bool stag_default = getenv("GLC_ATTN_STAG") != nullptr && atoi(getenv("GLC_ATTN_STAG")) != 0;
         if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);

@@ -72,6 +72,7 @@ struct glc_engine {
     bool w_presplit = false;        // weights of the split-f16 fp32 GEMMs are split once at load (encoder layers in fp32 mode; head projectors in every mode)
     bool dec_split = false;         // decoder backbone, fp32 mode: RoPE/layout pass writes split-f16 units, grouped-query attention on three-MFMA products
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
+    int prec_mask = 0;              // precision-budget switches (PM_* of glc_kernels.h; glc_debug_set_precision_mask): operands rounded to f16 in the group-split pipeline
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
     bool last_gs = false;           // the last forward ran the group-split pipeline
     bool ln_fused = true;           // group-split pipeline: LayerNorm folded into the GEMMs around it (GLC_LNF=0: separate LayerNorm kernels)
@@ -491,9 +492,11 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit;
         if (last) break;
         if (x_raw) { g.W = w.Wqkvf; g.bias = w.dq; g.a_stats = e->statsA; g.ln_c = w.cq; }
+        const int pm = gs ? e->prec_mask : 0;
+        g.prec = pm & 3;
         { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
         AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-        a.split = asplit; a.ctx_gs = gs;
+        a.split = asplit; a.ctx_gs = gs; a.prec = (pm >> 8) & 63;
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
@@ -502,6 +505,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
         if (x_raw) { const LayerW& wp = e->layers[l - 1]; o.r_stats = e->statsA; o.r_gamma = wp.ln2g; o.r_beta = wp.ln2b; }
         if (lnf) { o.C = e->H1; o.ln_part = e->ln_part; }      // raw sum -> H1 (group-split rows) + partials
+        o.prec = ((pm >> 2) & 3) | ((pm & PM_RESID) ? 4 : 0);
         { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
         { Prof p(e, PC_LN); KCHK(lnf ? glc_launch_ln_stats(st, e->ln_part, H / 64, e->statsB, M, H, c.ln_eps)
                                  : gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
@@ -509,10 +513,12 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
         if (lnf) { f1.W = w.W1f; f1.bias = w.d1; f1.a_stats = e->statsB; f1.ln_c = w.c1; }
+        f1.prec = (pm >> 4) & 3;
         { Prof p(e, PC_FFN1); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
         if (lnf) { f2.r_stats = e->statsB; f2.r_gamma = w.ln1g; f2.r_beta = w.ln1b; }
+        f2.prec = ((pm >> 6) & 3) | ((pm & PM_RESID) ? 4 : 0);
         // the next consumer of X takes raw rows only if it is a folded QKV of the pipeline (not the pruned last layer, which gathers normalised rows)
         const bool next_raw = lnf && l + 1 < c.layers && e->layers[l + 1].Wqkvf && !(prune && l + 1 == c.layers - 1);
         if (next_raw) { f2.C = e->X; f2.ln_part = e->ln_part; }
@@ -540,6 +546,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         // (group-split pipeline: the compact rows leave it here — plain fp32, the rest of this layer runs on the small-M kernels)
         if (gs) KCHK(glc_launch_gather_rows_gs(st, e->X, e->cls_pos, ccap, (float*)e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         else KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
+        if (gs) g.prec = e->prec_mask & 3;
         if (band_sel) g.q_tile_flag = e->tile_flag;       // the gather has flagged the query tiles that hold selected rows: the Q third skips the others
         KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false);
         if (band_sel) {
@@ -1156,6 +1163,15 @@ int glc_debug_set_ln_fused(glc_engine* e, int on) {
     e->ln_fused = on != 0;
     return 0;
 }
+/* Precision budget (developer): round operand groups of the default mode's group-split pipeline to f16 (PM_* bits of glc_kernels.h). */
+int glc_debug_set_precision_mask(glc_engine* e, int mask) {
+    if (!e || mask < 0 || mask >= (1 << 15)) { set_err("precision_mask: 15 bits"); return -1; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->prec_mask = mask;
+    return 0;
+}
+/* 256-tile GEMM: full-line ring stages on / off, process-wide (developer A/B switch; results are bit-identical either way). */
+int glc_debug_set_gemm_full_lines(int on) { glc_gemm_set_full_lines(on); return 0; }
 int glc_debug_keep_hidden(glc_engine* e, int on) { if (!e) return -1; e->keep_hidden = on != 0; return 0; }
 int glc_engine_set_prune_last_layer(glc_engine* e, int on) { if (!e) return -1; e->prune_last = on != 0; return 0; }
 int glc_debug_set_attention_impl(glc_engine* e, int impl) {
@@ -1187,7 +1203,11 @@ int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems)
  * which: 0 = auto (256-tile when possible), 1 = force the 128x128 kernel.  Returns ms per launch or <0. */
 float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which) {
     // which == 6: the group-split fp32-mode kernel (rows of [32 hi | 32 lo] f16 groups, 4 bytes per element; any engine dtype)
-    const bool gsb = which == 6;
+    const int which_in = which;
+    if (which >= 100) which %= 100;
+    const bool mxb = which == 9 || which == 10;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
+    const bool gsb = which == 6 || which == 8 || mxb;
+    const int mx_ws = glc_gx_weight_exponent(0.5f);
     if (!e || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (e->dtype == GLC_F32 && !gsb) || epi < EPI_BIAS || epi > EPI_RESID) { set_err("gemm_bench: bad args"); return -1.f; }
     if (M % 256 || N % 256 || K % 64) { set_err("gemm_bench: M,N %256, K %64 required"); return -1.f; }
     std::lock_guard<std::mutex> lk(e->mu);
@@ -1204,17 +1224,19 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         unsigned s = 12345u;
         for (size_t i = 0; i < nmax; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((float)(s >> 8) / 8388608.f - 1.f) * 0.5f; }
         if (hipMemcpy(tmp, h.data(), nmax * sizeof(float), hipMemcpyHostToDevice)) { set_err("gemm_bench: copy failed"); break; }
-        if (gsb) {      // fp32 values, split in place into the group-split image
+        if (gsb) {      // fp32 values, split in place into the group-split image (or the GX image)
             if (hipMemcpyAsync(A, tmp, nA * 4, hipMemcpyDeviceToDevice, e->stream) || hipMemcpyAsync(W, tmp, nW * 4, hipMemcpyDeviceToDevice, e->stream) ||
-                hipMemcpyAsync(R, tmp, nC * 4, hipMemcpyDeviceToDevice, e->stream) || glc_launch_presplit(e->stream, A, nA) ||
-                glc_launch_presplit(e->stream, W, nW) || glc_launch_presplit(e->stream, R, nC)) { set_err("gemm_bench: split failed"); break; }
+                hipMemcpyAsync(R, tmp, nC * 4, hipMemcpyDeviceToDevice, e->stream)) { set_err("gemm_bench: copy failed"); break; }
+            if (mxb ? (glc_launch_to_gx(e->stream, A, nA, 0) || glc_launch_to_gx(e->stream, W, nW, mx_ws) || glc_launch_to_gx(e->stream, R, nC, 0))
+                    : (glc_launch_presplit(e->stream, A, nA) || glc_launch_presplit(e->stream, W, nW) || glc_launch_presplit(e->stream, R, nC))) { set_err("gemm_bench: split failed"); break; }
         } else
         if (glc_launch_convert(e->stream, e->dtype, tmp, A, nA) || glc_launch_convert(e->stream, e->dtype, tmp, W, nW) ||
             glc_launch_convert(e->stream, e->dtype, tmp, R, nC)) { set_err("gemm_bench: convert failed"); break; }
         if (hipMemcpyAsync(bias, tmp, N * sizeof(float), hipMemcpyDeviceToDevice, e->stream)) break;
-        GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K;
+        GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K; g.mx_ws = mx_ws;
+        if (mxb && which_in >= 100) g.prio_mode = which_in / 100 - 1;      // which = 100 (1 + prio) + 9 | 10
         const char* m = nullptr;
-        auto launch = [&]() -> const char* { return gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : which == 5 ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
+        auto launch = [&]() -> const char* { return mxb ? glc_launch_gemm256x(e->stream, epi, g) : gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 5 || which == 7) ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
         if (m) { set_err(m); break; }
         if (hipEventRecord(e->t0, e->stream)) break;
@@ -1223,6 +1245,32 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         float t = 0.f;
         if (hipEventElapsedTime(&t, e->t0, e->t1)) break;
         ms = t / iters;
+        if (which == 7 || which == 8 || which == 10) {     // diagnostic: one stamped launch of the full-line 256-tile kernel (7: 16-bit operands, 8: group-split), EPI_BIAS
+            unsigned long long* dbuf = nullptr;
+            const size_t ns = 64 * 8 * 14;
+            if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
+                (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), e->stream);
+                GemmArgs gd = g; gd.stamps = dbuf;
+                const char* dm = which == 10 ? glc_launch_gemm256x(e->stream, EPI_BIAS, gd) : which == 8 ? glc_launch_gemm256s_gs(e->stream, EPI_BIAS, gd) : glc_launch_gemm256s(e->stream, e->dtype, EPI_BIAS, gd);
+                (void)hipStreamSynchronize(e->stream);
+                std::vector<unsigned long long> hs(ns);
+                if (!dm && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                    for (int grp = 0; grp < 2; ++grp) {       // wave group 0 (waves 0-3) / the late group (waves 4-7)
+                        double sg[12] = {0};
+                        for (int b = 0; b < 64; ++b) for (int w = 4 * grp; w < 4 * grp + 4; ++w) for (int k = 0; k < 12; ++k) sg[k] += (double)hs[((size_t)b * 8 + w) * 12 + k];
+                        const double n = 64 * 4, ng = sg[11] / n > 0 ? sg[11] / n : 1;
+                        fprintf(stderr, "[gemm256s stamps M=%d N=%d K=%d %s, waves %d-%d] cycles per group and wave: E: dma %.0f reads+wait %.0f barrier %.0f mfma %.0f barrier %.0f | "
+                                        "O: (dma %.0f) reads+wait %.0f barrier %.0f mfma %.0f barrier %.0f | total %.0f | clock %.0f MHz\n", M, N, K, which == 10 ? "MX" : which == 8 ? "group-split" : "16-bit", 4 * grp, 4 * grp + 3,
+                                sg[0] / n / ng, sg[1] / n / ng, sg[2] / n / ng, sg[3] / n / ng, sg[4] / n / ng, sg[5] / n / ng, sg[6] / n / ng, sg[7] / n / ng, sg[8] / n / ng, sg[9] / n / ng,
+                                (sg[0] + sg[1] + sg[2] + sg[3] + sg[4] + sg[5] + sg[6] + sg[7] + sg[8] + sg[9]) / n / ng, sg[10] / n / 10.0);
+                    }
+                    double pro = 0, epi = 0;
+                    for (size_t i = 0; i < 64 * 8; ++i) { pro += (double)hs[64 * 8 * 12 + 2 * i]; epi += (double)hs[64 * 8 * 12 + 2 * i + 1]; }
+                    fprintf(stderr, "[gemm256s stamps] per tile and wave: entry -> loop %.0f cycles, loop end -> stores retired %.0f cycles\n", pro / (64 * 8), epi / (64 * 8));
+                } else if (dm) fprintf(stderr, "[gemm256s stamps] %s\n", dm);
+                (void)hipFree(dbuf);
+            }
+        }
         if (which == 4) {     // diagnostic: one stamped launch of the 256-tile kernel; prints per-K-tile segment cycles (s_memtime ticks)
             unsigned long long* dbuf = nullptr;
             if (hipMalloc((void**)&dbuf, 64 * 8 * 4 * sizeof(unsigned long long)) == hipSuccess) {
@@ -1244,6 +1292,55 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
     } while (0);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(R); (void)hipFree(bias); (void)hipFree(tmp);
     return ms;
+}
+
+/* Developer check: the MX cross-term GEMM (gemm256x.hip) against the split-f16 GEMM (gemm256s.hip, GS) on the same random fp32 operands
+ * (A ~ U(-a_amp, a_amp), W ~ U(-w_amp, w_amp), bias), EPI_BIAS with plain fp32 outputs.  out[0] = max |C_mx - C_gs|, out[1] = max |C_gs|,
+ * out[2] = rms(C_mx - C_gs), out[3] = rms(C_gs).  Returns 0 or < 0. */
+int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, double* out) {
+    if (!e || !out || M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || K % 32) { set_err("gemm_mx_check: bad args"); return -1; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1);
+    const size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
+    float *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *C0 = nullptr, *C1 = nullptr, *bias = nullptr;
+    int rc = -1;
+    do {
+        if (hipMalloc((void**)&A, nA * 4) || hipMalloc((void**)&W, nW * 4) || hipMalloc((void**)&A2, nA * 4) || hipMalloc((void**)&W2, nW * 4) ||
+            hipMalloc((void**)&C0, nC * 4) || hipMalloc((void**)&C1, nC * 4) || hipMalloc((void**)&bias, (size_t)N * 4)) { set_err("gemm_mx_check: alloc failed"); break; }
+        std::vector<float> ha(nA), hw(nW), hb(N);
+        unsigned s = 777u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 8388608.f - 1.f; };
+        for (auto& v : ha) v = rnd() * a_amp;
+        for (auto& v : hw) v = rnd() * w_amp;
+        for (auto& v : hb) v = rnd() * 0.1f;
+        if (hipMemcpy(A, ha.data(), nA * 4, hipMemcpyHostToDevice) || hipMemcpy(W, hw.data(), nW * 4, hipMemcpyHostToDevice) ||
+            hipMemcpy(A2, ha.data(), nA * 4, hipMemcpyHostToDevice) || hipMemcpy(W2, hw.data(), nW * 4, hipMemcpyHostToDevice) ||
+            hipMemcpy(bias, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice)) { set_err("gemm_mx_check: copy failed"); break; }
+        const int ws = glc_gx_weight_exponent(w_amp);
+        const char* m = glc_launch_presplit(e->stream, A, nA);
+        if (!m) m = glc_launch_presplit(e->stream, W, nW);
+        if (!m) m = glc_launch_to_gx(e->stream, A2, nA, 0);
+        if (!m) m = glc_launch_to_gx(e->stream, W2, nW, ws);
+        GemmArgs g; g.bias = bias; g.Mpad = M; g.N = N; g.K = K; g.gs_c_plain = 1;
+        g.A = A; g.W = W; g.C = C0;
+        if (!m) m = glc_launch_gemm256s_gs(e->stream, EPI_BIAS, g);
+        g.A = A2; g.W = W2; g.C = C1; g.mx_ws = ws;
+        if (!m) m = glc_launch_gemm256x(e->stream, EPI_BIAS, g);
+        if (m) { set_err(m); break; }
+        std::vector<float> c0(nC), c1(nC);
+        if (hipStreamSynchronize(e->stream) || hipMemcpy(c0.data(), C0, nC * 4, hipMemcpyDeviceToHost) || hipMemcpy(c1.data(), C1, nC * 4, hipMemcpyDeviceToHost)) { set_err("gemm_mx_check: readback failed"); break; }
+        double md = 0, mr = 0, sd = 0, sr = 0;
+        for (size_t i = 0; i < nC; ++i) {
+            const double d = (double)c1[i] - (double)c0[i], r = c0[i];
+            if (!(fabs(d) <= md)) md = fabs(d);          // (NaN propagates into the maximum)
+            if (fabs(r) > mr) mr = fabs(r);
+            sd += d * d; sr += r * r;
+        }
+        out[0] = md; out[1] = mr; out[2] = sqrt(sd / nC); out[3] = sqrt(sr / nC);
+        rc = 0;
+    } while (0);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(C0); (void)hipFree(C1); (void)hipFree(bias);
+    return rc;
 }
 
 /* Developer microbenchmark: re-run the band attention kernel `iters` times on the Q/K/V^T that the last forward left in the

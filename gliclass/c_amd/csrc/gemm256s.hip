@@ -46,8 +46,30 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
 // ring and phases over 2K/32 stages, where stage 2s fetches the (hi, lo) and stage 2s + 1 the (lo, hi) 64-byte parts of group s of
 // the A and W rows (see the main loop: every part is fetched once, the a_hi fragments wait in registers).  Epilogues: GELU (exact erf form) / BIAS write C in the GS format; RESID reads the residual in the GS format and
 // writes plain fp32 (the LayerNorm input); QKV writes split-f16 fragment units [8 hi | 8 lo] (glc_common.h f16x8s).
-template <typename T, int EPI, bool VMODE, bool GS = false>
+// PD (GS only): precision-budget build (glc_debug_set_precision_mask): GemmArgs::prec drops operand lo halves at run time, which is
+// numerically the kernel with that operand rounded to f16 (the skipped terms are exact zeros) at unchanged cost.
+// FL ("full lines", round 3): operand-major ring stages.  The loop above it fetches, per 32-deep step, 64 bytes of every A row and
+// 64 bytes of every W row: each LDS-DMA wave-instruction covers 16 rows x HALF a 128-byte line, and every line is requested twice
+// (by two different stages).  The DMA path, not the MFMA count, bounds that loop (round-2 ablation: 760 of the ~1250 cycles of a
+// load phase are the 4 DMA pieces per wave; the vector-memory path pays per line touched).  Here a ring stage is ONE operand's rows
+// for one 128-byte "group" — a GS group [32 hi | 32 lo], or 64 k-values of a 16-bit row — so a wave-instruction moves 8 rows x 128 B
+// = 8 whole lines, each line exactly once: stage 2s = A rows of group s, stage 2s + 1 = W rows of group s, slot = stage & 3.
+// LDS image of a slot: [256 rows][128 B], physical 16-byte chunk c of row r holds logical chunk c ^ ((r >> 1) & 7) (source-side
+// swizzle: every ds_read_b128 lane group of a 16-row fragment read touches 16 distinct 16-B bank slots — two rows fill the 64 banks).
+// Schedule per group s (same two-phase step and wave-group stagger as above; MFMA order unchanged, results bit-identical):
+//   E: phase A = issue the DMA of group s + 1 (8 pieces per wave), read a[first half] + w[matching half]; phase B = 32 MFMAs
+//   O: phase A = read the other halves, wait for my pieces of group s + 1;                                  phase B = 64 (GS) / 32 MFMAs
+// Hazards (time slot of E_s phase A: 4s for group 0, 4s + 1 for the late group).  RAW: group s + 1 is first read at slot 4s + 4;
+// every wave waits for its own pieces (vmcnt(0): nothing else is in flight) in phase A of O_s, slot 4s + 2 / 4s + 3, before that
+// slot's barrier — at least a whole phase after requesting them.  WAR: group s + 1 lands in the slots of group s - 1, last read in
+// phase A of O_(s-1), slots 4s - 2 / 4s - 1, retired (lgkmcnt(0)) before those slots' barriers; the requests go out in slots 4s / 4s + 1.
+// DIAG (FL only): s_memtime stamps at the phase boundaries of the main loop, summed per wave (glc_debug_gemm_bench which = 7 prints them).
+template <typename T, int EPI, bool VMODE, bool GS = false, bool PD = false, bool FL = false, bool DIAG = false>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile0, int ntn) {
+    static_assert(!(PD && FL), "the precision-budget build uses the half-line loop");
+    static_assert(!DIAG || FL, "stamps exist in the full-line loop");
+    const unsigned long long t_entry = DIAG ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_loop0 = 0, t_loop1 = 0;
     static_assert(!GS || sizeof(T) == 2, "GS operands are f16 halves");
     typedef typename Frag<T>::type frag_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -132,6 +154,114 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
     //   RAW: step s+1 is first read at slot 2s+2; every wave makes its own pieces of step s+1 land (vmcnt) before the
     //        barrier that ends its A_s (slot <= 2s+1).
     //   WAR: DMA(s+3) reuses the slot of step s-1, last read at slot 2s-1 with lgkmcnt(0) before that slot's barrier.
+    if constexpr (FL) {
+        constexpr int LINE = 128;                  // bytes per row and group
+        const int rs = GS ? 2 * K : K;             // row stride in halves
+        const int ng = GS ? K / 32 : K / 64;       // groups
+        // DMA map: a wave-instruction lands 8 rows x 128 B; lane L lands at (row L >> 3, physical chunk L & 7) and fetches logical
+        // chunk (L & 7) ^ ((row >> 1) & 7).  Wave w moves rows [32 w + 8 i, + 8), i = 0..3, of the A tile and of the W tile; rows
+        // 16 apart share the swizzle, so two lane pointers per operand serve the four pieces.
+        const int lrow8 = lane >> 3, pch = lane & 7;
+        const T* fa[2];
+        const T* fw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 32 + i * 8 + lrow8;
+            const int lc = pch ^ ((row >> 1) & 7);
+            fa[i] = A + (size_t)(m0 + row) * rs + lc * 8;
+            fw[i] = W + (size_t)(n0 + row) * rs + lc * 8;
+        }
+        auto stage_fl = [&](int grp) {
+            unsigned char* sa = smem256 + ((2 * grp) & (NSLOT - 1)) * STAGE + (wave * 32) * LINE;
+            unsigned char* sw = smem256 + ((2 * grp + 1) & (NSLOT - 1)) * STAGE + (wave * 32) * LINE;
+            const size_t o = (size_t)grp * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(fa[i & 1] + (size_t)(i >> 1) * 16 * rs + o, sa + i * 8 * LINE);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(fw[i & 1] + (size_t)(i >> 1) * 16 * rs + o, sw + i * 8 * LINE);
+        };
+        // fragment read offsets inside a slot: row (.. + r16), logical chunk g (first half) or 4 + g (second half)
+        const int hsw = (r16 >> 1) & 7;
+        const int a_h0 = (wm * 128 + r16) * LINE + ((g ^ hsw) * 16), a_h1 = (wm * 128 + r16) * LINE + (((4 + g) ^ hsw) * 16);
+        const int b_h0 = (wn * 64 + r16) * LINE + ((g ^ hsw) * 16), b_h1 = (wn * 64 + r16) * LINE + (((4 + g) ^ hsw) * 16);
+        frag_t a0[8], a1[8], bq[4];
+        stage_fl(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // group 0 is in LDS for everyone
+        if (wm == 1) __builtin_amdgcn_s_barrier(); // the stagger
+        unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+        const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
+        t_loop0 = clk0;
+        auto stamp = [&](int k) __attribute__((always_inline)) {      // time since the previous stamp goes to segment k (k < 0: start)
+            if constexpr (DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (k >= 0) seg[k] += t - tlast;
+                tlast = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto sub = [&](const int s, const int odd) __attribute__((always_inline)) {
+            // ---- phase A ----
+            stamp(-1);
+            if (!odd && s + 1 < ng) stage_fl(s + 1);
+            stamp(5 * odd + 0);                    // seg 0: DMA issue
+            {
+                const unsigned char* sa = smem256 + ((2 * s) & (NSLOT - 1)) * STAGE;
+                const unsigned char* sw = smem256 + ((2 * s + 1) & (NSLOT - 1)) * STAGE;
+                // GS: E pairs a_hi with w_lo, O a_lo with w_hi (+ a_hi w_hi); 16-bit rows: E = first 32 k of both, O = second 32 k
+                const int bo = GS ? (odd ? b_h0 : b_h1) : (odd ? b_h1 : b_h0);
+                const int ao = odd ? a_h1 : a_h0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const frag_t*>(sw + bo + j * 16 * LINE);
+                if (!odd) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a0[i] = *reinterpret_cast<const frag_t*>(sa + ao + i * 16 * LINE);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a1[i] = *reinterpret_cast<const frag_t*>(sa + ao + i * 16 * LINE);
+                }
+            }
+            if (odd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(5 * odd + 1);                    // seg 1: fragment reads + waits
+            __builtin_amdgcn_s_barrier();
+            stamp(5 * odd + 2);                    // seg 2: barrier after phase A
+            // ---- phase B ----
+            __builtin_amdgcn_s_setprio(1);
+            if (odd) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { if (!VMODE) mma16(bq[j], a1[i], acc[i][j]); else mma16(a1[i], bq[j], acc[i][j]); }
+                }
+            }
+            if (!odd || GS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { if (!VMODE) mma16(bq[j], a0[i], acc[i][j]); else mma16(a0[i], bq[j], acc[i][j]); }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(5 * odd + 3);                    // seg 3: MFMA issue
+            __builtin_amdgcn_s_barrier();
+            stamp(5 * odd + 4);                    // seg 4: barrier after phase B
+        };
+        for (int s = 0; s < ng; ++s) { sub(s, 0); sub(s, 1); }
+        if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
+        if constexpr (DIAG) {
+            if (p.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {     // 64 workgroups of one XCD
+                unsigned long long* o = p.stamps + ((size_t)(blockIdx.x >> 3) * 8 + wave) * 12;
+                for (int k = 0; k < 10; ++k) o[k] = seg[k];
+                const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk0, dr = __builtin_amdgcn_s_memrealtime() - rt0;
+                o[10] = dr ? dc * 1000 / dr : 0; o[11] = ng;
+            }
+            t_loop1 = __builtin_amdgcn_s_memtime();
+        }
+    } else {
     stage(0);
     if (nk > 1) stage(1);
     if (nk > 2) stage(2);
@@ -158,6 +288,16 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const frag_t*>(sb + aoff + i * 16 * ROWB);
+                }
+                if constexpr (PD) {
+                    if (!odd && (p.prec & 2)) {      // W rounded to f16: the a_hi * w_lo term vanishes
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[j] = (frag_t)(T)0;
+                    }
+                    if (odd && (p.prec & 1)) {       // A rounded to f16: the a_lo * w_hi term vanishes
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) af[i] = (frag_t)(T)0;
+                    }
                 }
             }
             if (st + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -218,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
         __builtin_amdgcn_s_barrier();
     }
     if (!late) __builtin_amdgcn_s_barrier();   // pairs with group 1's last barrier
+    }
 
     // ---------------- epilogue ----------------
     // The accumulator layout gives a lane 4 consecutive columns of one row (8-byte pieces).  Storing that
@@ -334,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                         const T* rp = reinterpret_cast<const T*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 2 * N + (n >> 5) * 64 + (n & 31);
                         r[k] = *reinterpret_cast<const vec8T*>(rp);
                         rl[k] = *reinterpret_cast<const vec8T*>(rp + 32);
+                        if constexpr (PD) { if (p.prec & 4) rl[k] = (vec8T)(T)0; }      // residual stream rounded to f16
                         continue;
                     }
                     // "wide" lane map of the fp32-row epilogue: a lane owns columns [4 g8, +4) and [32 + 4 g8, +4) of the wave's 64, so that
@@ -350,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                         const vec4T hb = *reinterpret_cast<const vec4T*>(rp + 64), lb = *reinterpret_cast<const vec4T*>(rp + 96);
                         r[k] = (vec8T){ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
                         rl[k] = (vec8T){la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+                        if constexpr (PD) { if (p.prec & 4) rl[k] = (vec8T)(T)0; }
                     }
                 } else {
                     r[k] = *reinterpret_cast<const vec8T*>(reinterpret_cast<const T*>(p.resid) +
@@ -532,17 +675,35 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if constexpr (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tile's stores have left
+        if (p.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {
+            unsigned long long* o = p.stamps + 64 * 8 * 12 + ((size_t)(blockIdx.x >> 3) * 8 + wave) * 2;
+            o[0] = t_loop0 - t_entry;
+            o[1] = __builtin_amdgcn_s_memtime() - t_loop1;
+        }
+    }
 }
 
-template <typename T, int EPI, bool VMODE, bool GS = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+// full-line stages (kernel header): default on; GLC_GEMM_FL=0 selects the half-line loop (developer A/B switch; same results bit for bit)
+static std::atomic<int> g_full_lines{-1};
+static bool use_full_lines() {
+    int v = g_full_lines.load(std::memory_order_relaxed);
+    if (v < 0) { v = (getenv("GLC_GEMM_FL") == nullptr || atoi(getenv("GLC_GEMM_FL")) != 0) ? 1 : 0; g_full_lines.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+template <typename T, int EPI, bool VMODE, bool GS = false, bool PD = false, bool FL = false, bool DIAG = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+    if constexpr (GS && !PD && !FL) { if (a.prec) return launch_e<T, EPI, VMODE, GS, true, false>(st, a, n_tile0, ntn); }
+    if constexpr (!PD && !FL) { if (use_full_lines() && (GS || a.K % 64 == 0)) return launch_e<T, EPI, VMODE, GS, false, true>(st, a, n_tile0, ntn); }
+    if constexpr (FL && !DIAG && EPI == EPI_BIAS && !VMODE) { if (a.stamps) return launch_e<T, EPI, VMODE, GS, false, true, true>(st, a, n_tile0, ntn); }
     static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
-    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS, PD, FL, DIAG>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
     GemmArgs b = a;
     static const int ng_env = getenv("GLC_GEMM_NGROUP") ? atoi(getenv("GLC_GEMM_NGROUP")) : -1;      // developer A/B switch: 0 = row-major tile order
     b.n_group = 0;
     if (ng_env != 0 && ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);     // (6 N-tiles in 2 groups measured MORE fetch: A twice, W fitted anyway)
-    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
+    hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS, PD, FL, DIAG>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
     return nullptr;
 }
 template <typename T> const char* launch_t(hipStream_t st, int epi, const GemmArgs& a) {
@@ -609,6 +770,8 @@ const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmAr
     if (epi == EPI_SWIGLU && a.bias) return "gemm256s: the SwiGLU epilogue takes no bias";
     return dtype == GLC_DT_BF16 ? launch_t<bf16_t>(st, epi, a) : launch_t<f16_t>(st, epi, a);
 }
+
+void glc_gemm_set_full_lines(int on) { g_full_lines.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool glc_gemm_small_m(const GemmArgs& a) {
     static const int mode = getenv("GLC_GEMM_SMALL_M") ? atoi(getenv("GLC_GEMM_SMALL_M")) : 1;     // developer A/B switch (0 = off)

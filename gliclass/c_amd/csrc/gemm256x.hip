@@ -1,0 +1,474 @@
+// 256x256 GEMM of the default mode with MX cross terms (round 3): C = A . W^T on "GX" operand rows (glc_common.h):
+//   a * w = a_hi * w_hi            two v_mfma_f32_32x32x16_f16 per 32 k and 32x32 block            (2 x 32 cycles)
+//         + a_hi * w_lo + a_lo * w_hi   ONE v_mfma_scale_f32_32x32x64_f8f6f4 on the fp8 parts         (64 cycles)
+// instead of the six f16 MFMAs (192 cycles) of the split-f16 kernel (gemm256s.hip, GS).  Measured on the instruction mix alone
+// (scripts/probes/mx32_probe.hip): 128 vs 192 matrix-pipe cycles per product and a clock the chip holds 6 % higher (1.77 vs 1.67 GHz);
+// the round-3 stamps of the GS main loop showed its matrix pipe ~85 % busy, i.e. the pipe, not the loads, is what this removes.
+// Operand error: the cross terms are ~2^-11 of a product and come out to ~4 bits, so a product is good to ~2^-15 relative
+// (single f16: 2^-11; full split: 2^-21) — DESIGN.md has the measured per-label probability error of the whole forward.
+//
+// Structure = the full-line ring of gemm256s.hip (FL): ring stage 2s = A rows of 32-group s, stage 2s + 1 = W rows (one 128-byte GX
+// group per row: 8 whole lines per LDS-DMA wave-instruction), slot = stage & 3, LDS image [256 rows][128 B] with the 16-byte chunk
+// swizzle c ^ ((row >> 1) & 7); the same two-phase step and wave-group stagger, with EQUAL halves:
+//   E: phase A = request group s + 1 (8 pieces per wave), read the f16 fragments (8 + 4); phase B = 16 x 32x32x16 f16      (512 cycles)
+//   O: phase A = read the fp8 fragments (4 + 2 operands of 32 B), wait for my pieces;     phase B =  8 x 32x32x64 scaled   (512 cycles)
+// Hazards: as argued in gemm256s.hip (FL).  Fragment maps: f16 32x32x16 lane (c = l & 31, h = l >> 5) holds row c, k = 16 ks + 8 h + j
+// = chunk 2 ks + h of the group; fp8 32x32x64 lane (c, h) holds bytes [0,16) = MX block 0, slots 16 h .. 16 h + 15, and [16,32) = block 1,
+// same slots (probe: byte y <-> k = 16 h + (y & 15) + 32 (y >> 4)); the scale of block b of row c is taken from lane c + 32 b.  Block 0
+// pairs a_hi8 with w_lo8, block 1 a_lo8 with w_hi8, both over k = 16 h .. 16 h + 15 of the group: A lane = [chunk 6 + h | chunk 4 + h],
+// W lane = [chunk 4 + h | chunk 6 + h].
+// Accumulators are 32x32 blocks, acc[I][J]: non-transposed launches D[n][m] (lane = m, registers = n: 4 consecutive n per register
+// quad), the V third D[m][n].  Epilogues as gemm256s.hip (LDS-staged 16-byte stores, LayerNorm fold, residual prefetch), reading and
+// writing GX rows where that kernel has GS rows.
+#include <stdlib.h>
+#include "glc_common.h"
+#include "glc_kernels.h"
+#include "glc_layout.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256;
+constexpr int LINE = 128;                  // bytes per row and group
+constexpr int STAGE = TM * LINE;           // 32 KiB: one operand's rows of one group
+constexpr int NSLOT = 4;
+constexpr int EPI_PATCH = 9216;            // bytes of wave-private fp32 epilogue staging
+extern __shared__ __attribute__((aligned(16))) unsigned char smem256x[];
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+}
+
+template <int EPI, bool VMODE, bool DIAG = false>
+__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int c32 = lane & 31, h = lane >> 5;
+    const int K = p.K, N = p.N;
+    const unsigned long long t_entry = DIAG ? __builtin_amdgcn_s_memtime() : 0;
+
+    // XCD-aware tile order (gemm256s.hip)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int mt = tile / ntn, nt = tile % ntn;
+    if (p.n_group > 0) {
+        const int mts = nwg / ntn, mpx = mts >> 3, nb = p.n_group;
+        const int i = bid >> 3, per = mpx * nb;
+        const int cg = i / per, r = i - cg * per;
+        mt = xcd * mpx + r / nb;
+        nt = cg * nb + r % nb;
+    }
+    const int m0 = mt * TM, n0 = (n_tile0 + nt) * TN;
+    if constexpr (EPI == EPI_QKV && !VMODE) {
+        if (p.q_tile_flag && n0 < p.H) {                // Q third, pruned last layer: nobody reads query tiles without selected rows
+            const unsigned long long f8 = *reinterpret_cast<const unsigned long long*>(p.q_tile_flag + (m0 >> 5));
+            if (f8 == 0ull) return;
+        }
+    }
+
+    const unsigned char* __restrict__ A = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* __restrict__ W = reinterpret_cast<const unsigned char*>(p.W);
+    const size_t rsb = (size_t)4 * K;          // row stride in bytes
+    const int ng = K / 32;
+
+    // DMA map (FL): lane L lands at (row L >> 3, physical chunk L & 7) of an 8-row piece and fetches logical chunk (L & 7) ^ ((row >> 1) & 7)
+    const int lrow8 = lane >> 3, pch = lane & 7;
+    const unsigned char* fa[2];
+    const unsigned char* fw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 8 + lrow8;
+        const int lc = pch ^ ((row >> 1) & 7);
+        fa[i] = A + (size_t)(m0 + row) * rsb + lc * 16;
+        fw[i] = W + (size_t)(n0 + row) * rsb + lc * 16;
+    }
+    auto stage_fl = [&](int grp) {
+        unsigned char* sa = smem256x + ((2 * grp) & (NSLOT - 1)) * STAGE + (wave * 32) * LINE;
+        unsigned char* sw = smem256x + ((2 * grp + 1) & (NSLOT - 1)) * STAGE + (wave * 32) * LINE;
+        const size_t o = (size_t)grp * LINE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(fa[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sa + i * 8 * LINE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(fw[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sw + i * 8 * LINE);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets inside a slot
+    const int hsw = (c32 >> 1) & 7;
+    const int arow = (wm * 128 + c32) * LINE, wrow = (wn * 64 + c32) * LINE;
+    const int ck0 = ((0 + h) ^ hsw) * 16, ck1 = ((2 + h) ^ hsw) * 16;       // f16 k-steps 0 / 1: logical chunks h / 2 + h
+    const int clo = ((4 + h) ^ hsw) * 16, chi = ((6 + h) ^ hsw) * 16;       // fp8 lo8 / hi8 of k = 16 h .. 16 h + 15
+    // e8m0 scales, one per MX block: block 0 from lanes 0-31, block 1 from lanes 32-63.  A (activations, exponent 0): hi8 | lo8;  W: lo8 | hi8.
+    const int sc_a = h ? 127 - GLC_GX_SHIFT : 127;
+    const int sc_w = h ? 127 - p.mx_ws : 127 - p.mx_ws - GLC_GX_SHIFT;
+
+    unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, t_loop1 = 0;
+    const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if constexpr (DIAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (k >= 0) seg[k] += t - tlast;
+            tlast = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f16x8 a16[4][2], w16[2][2];
+    i32x8 xa[4], xw[2];
+    const int pm = p.prio_mode;               // 0: no priorities; 1: MFMA phase at priority 1; 2: load phase at priority 2; 3: the late wave group at priority 1 throughout
+    if (pm == 3 && wm == 1) __builtin_amdgcn_s_setprio(1);
+    stage_fl(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // group 0 is in LDS for everyone
+    if (wm == 1) __builtin_amdgcn_s_barrier(); // the stagger
+    auto ld32 = [&](const unsigned char* q0, int o0, int o1) __attribute__((always_inline)) {      // two 16-byte chunks -> one 32-byte MX operand
+        const i32x4 t0 = *reinterpret_cast<const i32x4*>(q0 + o0);
+        const i32x4 t1 = *reinterpret_cast<const i32x4*>(q0 + o1);
+        i32x8 r;
+        r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+        return r;
+    };
+    auto sub = [&](const int s, const int odd) __attribute__((always_inline)) {
+        // ---- phase A ----
+        stamp(-1);
+        if (pm == 2) __builtin_amdgcn_s_setprio(2);
+        if (!odd && s + 1 < ng) stage_fl(s + 1);
+        stamp(5 * odd + 0);
+        {
+            const unsigned char* sa = smem256x + ((2 * s) & (NSLOT - 1)) * STAGE + arow;
+            const unsigned char* sw = smem256x + ((2 * s + 1) & (NSLOT - 1)) * STAGE + wrow;
+            if (!odd) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    w16[j][0] = *reinterpret_cast<const f16x8*>(sw + j * 32 * LINE + ck0);
+                    w16[j][1] = *reinterpret_cast<const f16x8*>(sw + j * 32 * LINE + ck1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a16[i][0] = *reinterpret_cast<const f16x8*>(sa + i * 32 * LINE + ck0);
+                    a16[i][1] = *reinterpret_cast<const f16x8*>(sa + i * 32 * LINE + ck1);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xw[j] = ld32(sw + j * 32 * LINE, clo, chi);      // [w_lo8 | w_hi8]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[i] = ld32(sa + i * 32 * LINE, chi, clo);      // [a_hi8 | a_lo8]
+            }
+        }
+        if (odd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (pm == 2) __builtin_amdgcn_s_setprio(0);
+        stamp(5 * odd + 1);
+        __builtin_amdgcn_s_barrier();
+        stamp(5 * odd + 2);
+        // ---- phase B ----
+        if (pm == 1) __builtin_amdgcn_s_setprio(1);
+        if (!odd) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (!VMODE) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[j][ks], a16[i][ks], acc[i][j], 0, 0, 0);      // D[n][m]
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][ks], w16[j][ks], acc[i][j], 0, 0, 0);            // D[m][n]
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!VMODE) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xw[j], xa[i], acc[i][j], 0, 0, 0, sc_w, 0, sc_a);
+                    else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[i], xw[j], acc[i][j], 0, 0, 0, sc_a, 0, sc_w);
+                }
+        }
+        if (pm == 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(5 * odd + 3);
+        __builtin_amdgcn_s_barrier();
+        stamp(5 * odd + 4);
+    };
+    for (int s = 0; s < ng; ++s) { sub(s, 0); sub(s, 1); }
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
+    if constexpr (DIAG) {
+        if (p.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {
+            unsigned long long* o = p.stamps + ((size_t)(blockIdx.x >> 3) * 8 + wave) * 12;
+            for (int k = 0; k < 10; ++k) o[k] = seg[k];
+            const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk0, dr = __builtin_amdgcn_s_memrealtime() - rt0;
+            o[10] = dr ? dc * 1000 / dr : 0; o[11] = ng;
+        }
+        t_loop1 = __builtin_amdgcn_s_memtime();
+    }
+
+    // ---------------- epilogue ----------------
+    typedef f16_t T;
+    typedef __attribute__((ext_vector_type(8))) T vec8T;
+    const float* __restrict__ bias = p.bias;
+    float* stg = reinterpret_cast<float*>(smem256x + wave * EPI_PATCH);
+    const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;
+    constexpr float kHi = 1.0f, kLo = (float)(1 << GLC_GX_SHIFT), kInvLo = 1.0f / (float)(1 << GLC_GX_SHIFT);       // activation rows: exponent 0
+    if constexpr (!VMODE) {
+        // D[n = 32 J + 8 q + 4 h + e][m = 32 I + c32]; patch [32 rows m][64 cols n], row stride 68 floats
+        const int which = (EPI == EPI_QKV) ? n0 / p.H : 0;
+        const bool lnf = EPI != EPI_RESID && p.a_stats != nullptr;
+        f32x4 bj[2][4], cj[2][4];
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nn = n0 + wn * 64 + 32 * J + 8 * q + 4 * h;
+                bj[J][q] = bias ? *reinterpret_cast<const f32x4*>(bias + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                cj[J][q] = (lnf && p.ln_c) ? *reinterpret_cast<const f32x4*>(p.ln_c + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        float rg[8], rb[8];
+        const bool rln = EPI == EPI_RESID && p.r_stats != nullptr;
+        const bool gxout = EPI == EPI_RESID && p.ln_part != nullptr;      // raw GX rows + statistics partials out
+        if constexpr (EPI == EPI_RESID) {
+            if (rln) {
+                const int nb = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { rg[e] = p.r_gamma[nb + e]; rb[e] = p.r_beta[nb + e]; }
+            }
+        }
+        // residual rows (GX) one 32-row chunk ahead of their use: lane = 8 consecutive columns
+        gs_h8 rpre[4]; u32x2 rpre_lo[4]; float2 rst_pre[4];
+        auto load_resid = [&](int c, gs_h8 (&r)[4], u32x2 (&rl)[4], float2 (&rst)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
+                if (rln) rst[k] = p.r_stats[m0 + wm * 128 + c * 32 + row];
+                const int n = n0 + wn * 64 + g8 * 8;
+                const unsigned char* rp = reinterpret_cast<const unsigned char*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 4 * N + (n >> 5) * 128;
+                r[k] = *reinterpret_cast<const gs_h8*>(rp + (n & 31) * 2);
+                rl[k] = *reinterpret_cast<const u32x2*>(rp + 64 + (n & 31));
+            }
+        };
+        if (EPI == EPI_RESID) load_resid(0, rpre, rpre_lo, rst_pre);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            gs_h8 rcur[4]; u32x2 rcur_lo[4]; float2 rst_cur[4];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rcur[k] = rpre[k]; rcur_lo[k] = rpre_lo[k]; rst_cur[k] = rst_pre[k]; }
+                if (c + 1 < 4) load_resid(c + 1, rpre, rpre_lo, rst_pre);
+            }
+            const float2 sm = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + c32] : make_float2(0.f, 1.f);
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[c][J][4 * q], acc[c][J][4 * q + 1], acc[c][J][4 * q + 2], acc[c][J][4 * q + 3]};
+                    if constexpr (EPI != EPI_RESID) {
+                        if (lnf) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = sm.y * (v[r] - sm.x * cj[J][q][r]);
+                        }
+                    }
+                    v += bj[J][q];
+                    if (EPI == EPI_GELU) { v[0] = glc_gelu(v[0]); v[1] = glc_gelu(v[1]); v[2] = glc_gelu(v[2]); v[3] = glc_gelu(v[3]); }
+                    *reinterpret_cast<f32x4*>(stg + c32 * 68 + 32 * J + 8 * q + 4 * h) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 68 + g8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int m = m0 + wm * 128 + c * 32 + row;
+                const int n = n0 + wn * 64 + g8 * 8;
+                if constexpr (EPI == EPI_RESID) {
+                    float r[8];
+                    gx_decode8(rcur[k], rcur_lo[k], kInvLo, r);
+                    if (rln) {           // raw residual row: LayerNorm on the fly
+                        const float2 rs = rst_cur[k];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (r[e] - rs.x) * rs.y * rg[e] + rb[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    }
+                    if (gxout) {
+                        // raw GX row out + this 64-column block's (sum, squared deviations from the block mean) of the row (gemm256s.hip)
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s1 += v[e];
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) s1 += __shfl_xor(s1, o, 64);
+                        const float bm = s1 * (1.0f / 64.0f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float dv = v[e] - bm; s2 += dv * dv; }
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) s2 += __shfl_xor(s2, o, 64);
+                        if (g8 == 0) p.ln_part[(size_t)m * (N >> 6) + ((n0 + wn * 64) >> 6)] = make_float2(s1, s2);
+                        gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo);
+                    } else {             // plain fp32 row (LayerNorm input)
+                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
+                        *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    }
+                } else if constexpr (EPI == EPI_QKV) {
+                    if (m < p.Mvalid) {
+                        vec8T o, ol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { o[e] = (T)v[e]; ol[e] = (T)(v[e] - (float)o[e]); }
+                        int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                        while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                        const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;
+                        const int bh = b * p.nh + hh;
+                        const size_t off = which == 0 ? glc_qoff(p.Sp, bh, sq, dd) : glc_koff(p.Sp, bh, sq, dd);
+                        T* base = reinterpret_cast<T*>(which == 0 ? p.Qh : p.Kh);
+                        *reinterpret_cast<vec8T*>(base + 2 * off) = o;          // split-f16 unit [8 hi | 8 lo]
+                        *reinterpret_cast<vec8T*>(base + 2 * off + 8) = ol;
+                    }
+                } else {
+                    if (p.gs_c_plain) {
+                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
+                        *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        // V third: D[m = 32 I + 8 q + 4 h + e][n = 32 J + c32]; patch [64 rows dd][32 cols key], row stride 36 floats
+        float bn[2], cn[2] = {0.f, 0.f};
+        const bool lnf = p.a_stats != nullptr;
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            bn[J] = bias ? bias[n0 + wn * 64 + 32 * J + c32] : 0.f;
+            if (lnf && p.ln_c) cn[J] = p.ln_c[n0 + wn * 64 + 32 * J + c32];
+        }
+        const int hh = (n0 + wn * 64 - 2 * p.H) >> 6;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[c][J][4 * q], acc[c][J][4 * q + 1], acc[c][J][4 * q + 2], acc[c][J][4 * q + 3]};
+                    if (lnf) {      // accumulator rows m0 + 128 wm + 32 c + 8 q + 4 h + r
+                        const float2* sp = p.a_stats + m0 + wm * 128 + c * 32 + 8 * q + 4 * h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float2 sm = sp[r]; v[r] = sm.y * (v[r] - sm.x * cn[J]); }
+                    }
+                    v[0] += bn[J]; v[1] += bn[J]; v[2] += bn[J]; v[3] += bn[J];
+                    *reinterpret_cast<f32x4*>(stg + (32 * J + c32) * 36 + 8 * q + 4 * h) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, dd = idx >> 2, kg = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + dd * 36 + kg * 8 + 4);
+                vec8T o, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (T)lo[e]; o[4 + e] = (T)hi[e];
+                    ol[e] = (T)(lo[e] - (float)o[e]); ol[4 + e] = (T)(hi[e] - (float)o[4 + e]);
+                }
+                const int m = m0 + wm * 128 + c * 32 + kg * 8;           // first of 8 consecutive keys
+                if (m < p.Mvalid) {
+                    int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                    while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                    const size_t off = glc_voff(p.Sp, b * p.nh + hh, dd, sq);
+                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + 2 * off) = o;
+                    *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + 2 * off + 8) = ol;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if constexpr (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {
+            unsigned long long* o = p.stamps + 64 * 8 * 12 + ((size_t)(blockIdx.x >> 3) * 8 + wave) * 2;
+            o[0] = clk0 - t_entry;
+            o[1] = __builtin_amdgcn_s_memtime() - t_loop1;
+        }
+    }
+}
+
+template <int EPI, bool VMODE, bool DIAG = false> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+    if constexpr (!DIAG && EPI == EPI_BIAS && !VMODE) { if (a.stamps) return launch_x<EPI, VMODE, true>(st, a, n_tile0, ntn); }
+    static std::atomic<unsigned> lds_ok{0};
+    if (!glc_raise_lds_limit(gemm256x_kernel<EPI, VMODE, DIAG>, NSLOT * STAGE, lds_ok)) return "gemm256x: cannot raise the dynamic LDS limit";
+    const int grid = (a.Mpad / TM) * ntn;
+    GemmArgs b = a;
+    b.n_group = 0;
+    static const int prio_env = getenv("GLC_GEMM_PRIO") ? atoi(getenv("GLC_GEMM_PRIO")) : 1;      // developer A/B switch
+    b.prio_mode = a.prio_mode >= 0 ? a.prio_mode : prio_env;
+    if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);      // wide N: as gemm256s.hip
+    hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE, DIAG>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
+    return nullptr;
+}
+
+// fp32 values -> GX rows in place (weights at load): exponent sc on the fp8 parts
+__global__ __launch_bounds__(256) void to_gx_kernel(float* __restrict__ w, size_t ngroups, float k_hi, float k_lo) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    float* base = w + gi * 32;
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + 4 * i);      // the whole group is read before it is overwritten
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x[8] = {v[2 * i][0], v[2 * i][1], v[2 * i][2], v[2 * i][3], v[2 * i + 1][0], v[2 * i + 1][1], v[2 * i + 1][2], v[2 * i + 1][3]};
+        gx_store8(reinterpret_cast<unsigned char*>(base), 8 * i, x, k_hi, k_lo);
+    }
+}
+
+}  // namespace
+
+bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
+    if (!(a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 32 == 0)) return false;
+    if (a.mx_ws < -40 || a.mx_ws > 60) return false;
+    if (epi == EPI_QKV) return a.H % 256 == 0 && a.N == 3 * a.H && a.Sp % 64 == 0 && a.Sp >= 64 && a.nh * 64 == a.H;
+    return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID;
+}
+
+const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a) {
+    if (!glc_gemm256x_supported(a, epi)) return "gemm256x: unsupported shape";
+    if (!a.A || !a.W) return "gemm256x: null operand";
+    if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256x: null QKV output"; }
+    else if (!a.C) return "gemm256x: null output";
+    if (epi == EPI_RESID && !a.resid) return "gemm256x: null residual";
+    const int ntn = a.N / TN;
+    switch (epi) {
+        case EPI_BIAS: return launch_x<EPI_BIAS, false>(st, a, 0, ntn);
+        case EPI_GELU: return launch_x<EPI_GELU, false>(st, a, 0, ntn);
+        case EPI_RESID: return launch_x<EPI_RESID, false>(st, a, 0, ntn);
+        case EPI_QKV: {
+            const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
+            const char* m = launch_x<EPI_QKV, false>(st, a, nq, nqk - nq);
+            return m ? m : launch_x<EPI_QKV, true>(st, a, nqk, ntn - nqk);
+        }
+    }
+    return "gemm256x: bad epilogue";
+}
+
+// In place: n fp32 values (n % 32 == 0) -> GX rows with fp8 exponent sc (glc_common.h): weights at load (sc = glc_gx_weight_exponent),
+// activations in tests (sc = 0).
+const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc) {
+    if (!w || n % 32) return "to_gx: element count must be a multiple of 32";
+    if (sc < -40 || sc > 60) return "to_gx: exponent out of range";
+    const size_t groups = n / 32;
+    if (groups) hipLaunchKernelGGL(to_gx_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (float*)w, groups, ldexpf(1.0f, sc), ldexpf(1.0f, sc + GLC_GX_SHIFT));
+    return nullptr;
+}

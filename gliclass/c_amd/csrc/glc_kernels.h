@@ -45,7 +45,17 @@ struct GemmArgs {
     float2* ln_part = nullptr;
     const float2* a_stats = nullptr; const float* ln_c = nullptr;
     const float2* r_stats = nullptr; const float* r_gamma = nullptr; const float* r_beta = nullptr;
+    // precision-budget switches (glc_debug_set_precision_mask; GS kernels): bit 0 = A rounded to f16 (lo halves dropped), bit 1 = W,
+    // bit 2 = the GS residual rows
+    int prec = 0;
+    int prio_mode = -1;                     // gemm256x: wave priority policy of the main loop (-1: default / GLC_GEMM_PRIO; developer A/B)
+    int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
 };
+// Precision-budget mask of an engine (developer, gliclass_hip.h glc_debug_set_precision_mask): a set bit rounds that operand of the
+// default mode's group-split pipeline to f16 by dropping its lo halves (numerically identical to the cheaper kernel that never
+// fetches them).  GEMM classes x (A, W); attention operand tensors; the GS residual reads of the two residual GEMMs.
+enum { PM_QKV_A = 1 << 0, PM_QKV_W = 1 << 1, PM_AO_A = 1 << 2, PM_AO_W = 1 << 3, PM_F1_A = 1 << 4, PM_F1_W = 1 << 5, PM_F2_A = 1 << 6, PM_F2_W = 1 << 7,
+       PM_Q = 1 << 8, PM_K = 1 << 9, PM_V = 1 << 10, PM_P = 1 << 11, PM_PQ = 1 << 12, PM_PK = 1 << 13, PM_RESID = 1 << 14 };
 // (sum, M2) partials of 64-column blocks [M][nparts] -> (mean, 1 / sqrt(var + eps)) [M] over rows of H = 64 nparts values (rows.hip; Chan's merge in double, fixed order)
 const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps, int rms = 0);   // rms: (0, 1 / sqrt(E[x^2] + eps))
 // decoder backbone: plain fp32 rows -> raw group-split rows + RMSNorm statistics (0, rstd) per row
@@ -55,6 +65,7 @@ bool glc_gemm256_supported(int dtype, const GemmArgs& a);
 const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a);    // 256x256 tile, 16-bit T
 const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmArgs& a);   // 256x256 tile, staggered wave groups (gemm256s.hip)
 bool glc_gemm_use_stagger();
+void glc_gemm_set_full_lines(int on);       // gemm256s.hip: full-line (operand-major) ring stages on / off, process-wide (developer A/B; default on, GLC_GEMM_FL=0)
 bool glc_gemm_small_m(const GemmArgs& a);   // gemm256s.hip: too few 256x256 tiles for this device -> use the 128x128 kernel
 // picks the 256x256 LDS-DMA kernel when the shape allows it, else the 128x128 one
 inline const char* glc_launch_gemm_auto(hipStream_t st, int dtype, int epi, const GemmArgs& a) {
@@ -81,6 +92,18 @@ const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* 
 // (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) on the 16-bit kernel's ring, every 64-byte part fetched once.  EPI_GELU / EPI_BIAS: C in the GS format;
 // EPI_RESID: resid in the GS format, C plain fp32 (the LayerNorm input); EPI_QKV: Q / K / V^T as split-f16 units (qkv_split).
 bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi);
+// MX cross-term GEMM on GX rows (gemm256x.hip; glc_common.h has the format): A [Mpad, K] and W [N, K] as GX rows (W with fp8 exponent
+// mx_ws), one f16 MFMA pair + one block-scaled fp8 MFMA per product.  EPI_GELU / EPI_BIAS: C as GX rows (gs_c_plain: plain fp32);
+// EPI_RESID: resid as GX rows, C raw GX rows + ln_part, or plain fp32; EPI_QKV: split-f16 units; LayerNorm fold arguments as gemm256s.
+bool glc_gemm256x_supported(const GemmArgs& a, int epi);
+const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a);
+const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc);       // in place: n fp32 values -> GX rows, fp8 exponent sc
+// fp8 exponent for a weight tensor whose largest magnitude is maxabs: 2^sc maxabs <= 240 (e4m3 saturates at 448)
+inline int glc_gx_weight_exponent(float maxabs) {
+    if (!(maxabs > 0.f)) return 0;
+    int sc = (int)floorf(log2f(240.0f / maxabs));
+    return sc < -30 ? -30 : (sc > 40 ? 40 : sc);
+}
 const char* glc_launch_gemm256s_gs(hipStream_t st, int epi, const GemmArgs& a);
 
 // Embedding gather + LayerNorm + mask (modeling_deberta_v2.py:533,550,552-559) on the padded
@@ -118,6 +141,7 @@ struct AttnArgs {
     int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
     int ctx_gs = 0;                                   // workgroup-shared kernel, split operands: write CTX rows in the GS format (see below)
     int ksplit = 0;                                   // per-wave band kernel with tile_flag: a workgroup with ONE flagged query tile splits that tile's keys over its 4 waves
+    int prec = 0;                                     // workgroup-shared kernel, split units: (engine mask >> 8) & 63 — bits Q, K, V, P, PQ, PK rounded to f16
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel, one independent wave per 32-query tile (attention.hip)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);

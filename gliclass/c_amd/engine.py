@@ -111,6 +111,11 @@ class Engine:
         if self.L.glc_debug_set_ln_fused(self.h, int(bool(on))) != 0:
             raise self._err("glc_debug_set_ln_fused")
 
+    def set_precision_mask(self, mask):
+        """default mode, group-split pipeline: round operand groups to f16 (bits: include/gliclass_hip.h glc_debug_set_precision_mask)"""
+        if self.L.glc_debug_set_precision_mask(self.h, int(mask)) != 0:
+            raise self._err("glc_debug_set_precision_mask")
+
     def keep_hidden(self, on=True):
         self.L.glc_debug_keep_hidden(self.h, int(on))
 

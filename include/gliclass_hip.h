@@ -138,6 +138,12 @@ int glc_debug_last_forward_group_split(const glc_engine* e);
  * runs on weights with gamma folded in and finishes (LN(x) W^T + b) in its epilogue) or as kernels of its own (0). */
 int glc_debug_set_ln_fused(glc_engine* e, int on);
 int glc_debug_last_forward_ln_folded(const glc_engine* e);      /* 1: the last forward ran with the norm folded into its GEMMs (every mode) */
+/* Precision budget of the default mode (developer; scripts/precision_budget.py): a set bit rounds one operand group of the group-split
+ * pipeline to f16 by dropping its lo halves — numerically the cheaper kernel that never fetches them.  Bits 0-7: (A, W) of the QKV,
+ * attention-output, FFN1, FFN2 projections; 8-13: attention Q, K, V^T, P, PQ rows, PK rows; 14: the residual rows. */
+int glc_debug_set_precision_mask(glc_engine* e, int mask);
+/* 256-tile GEMM ring: full-line (operand-major) stages on / off, process-wide developer A/B switch; bit-identical results. */
+int glc_debug_set_gemm_full_lines(int on);
 
 /* clamp(bucket(q-k)+span, 0, 2span-1) for q-k in [-(S-1), S-1] at out[q-k+S-1] (float32 math as
  * torch).  Pure host function (no GPU needed). */
@@ -145,6 +151,8 @@ void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out);
 
 /* Developer microbenchmark of one GEMM shape (16-bit engines): ms per launch, <0 on error. */
 float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which);
+/* Developer check: MX cross-term GEMM against the split-f16 GEMM on the same random operands (engine.hip). */
+int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, double* out);
 /* Developer microbenchmark of the band attention kernel on the workspace of the last forward (see engine.hip). */
 float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum);
 

@@ -3,8 +3,9 @@
 /root/reference/src/model.c:122-207) at BASELINE.json's config c3 — gliclass-base shape, batch 64,
 seq 1024, 8 labels — one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f16|bf16] [--config base|small|large|qwen-1.5b]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f16|bf16] [--config base|small|large|qwen-1.5b|c2|c3|c4|c5]
                   [--batch B] [--seq S] [--labels C] [--scaling weak|strong]
+  (--config c2 .. c5 = BASELINE.json's configs as one flag: c4 = large, one global batch of 256 split over the ranks, strong scaling)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Launched WITHOUT a torch.distributed environment and with --gpus N > 1, this script starts the N ranks itself (fresh child
@@ -303,9 +304,10 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
                 mfma_per_product=mpp, executed_mfma_frac=round(per[dom]["tflops"] * mpp / peak, 4),
                 e2e_achieved=round(e2e, 1), e2e_peak=peak, e2e_frac=round(e2e / peak, 4),
                 executed_flops_frac=round(executed / peak, 4),
-                # MFMA utilisation of the whole forward: FLOPs the matrix pipes really execute (every product of this mode costs
-                # mfma_per_product MFMAs; the pruned last layer counted at its real size) over the dense f16 / bf16 MFMA peak
-                mfma_utilisation=round(executed * mpp / peak, 4), per_kernel=per)
+                # matrix-pipe occupancy of the whole forward, NOT an efficiency figure: the FLOPs the pipes execute — every product of
+                # this mode costs mfma_per_product MFMAs, i.e. x3 self-inflicted work in the default mode — over the f16 peak.  The
+                # number that counts against the north star is e2e_frac (algorithmic FLOPs).
+                executed_mfma_whole_forward_frac=round(executed * mpp / peak, 4), per_kernel=per)
 
 
 def prob_err(a, b):
@@ -324,12 +326,25 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--labels", type=int, default=8)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    ap.add_argument("--dump-logits", default="", help=argparse.SUPPRESS)      # tests: rank 0 writes the step's [B, C] logits (.npy)
     ap.add_argument("--cpu-seqs", type=int, default=12, help="sequences timed on the CPU baseline, N=1 only (0 = skip); 12 = about 10 s on a 16-CPU share")
     ap.add_argument("--cpu-seqs-8", type=int, default=6, help="sequences of the OMP_NUM_THREADS=8 leg of the CPU baseline")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)        # CPU rehearsal of the multi-rank path (tests): gloo + StubRunner
     args = ap.parse_args()
+    # BASELINE.json's configs as one flag each (explicit --batch / --seq / --scaling still win where given on the command line)
+    alias = {"c2": ("small", 8, 512, "weak"), "c3": ("base", 64, 1024, "weak"), "c4": ("large", 256, 1024, "strong"), "c5": ("qwen-1.5b", 16, 2048, "weak")}
+    if args.config in alias:
+        cname, ab, asq, asc = alias[args.config]
+        given = " ".join(sys.argv[1:])
+        args.config = cname
+        if "--batch" not in given: args.batch = ab
+        if "--seq" not in given: args.seq = asq
+        if args.scaling is None: args.scaling = asc
+    scaling_defaulted = args.scaling is None
+    if args.scaling is None:
+        args.scaling = "weak"
 
     # ---- the N ranks: from the launcher's environment, or started here ----
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -435,6 +450,14 @@ def main():
         for _ in range(args.steps):
             runner.step()
         ev_ms = float(hipl.glc_timer_stop_ms(h)) / args.steps
+        # per-step distribution (SURVEY.md §8d protocol: median + p10 / p90): every step timed on its own with HIP events on the engine's stream
+        lap = []
+        for _ in range(max(5, min(args.steps, 20))):
+            hipl.glc_timer_start(h)
+            runner.step()
+            lap.append(float(hipl.glc_timer_stop_ms(h)))
+        lap.sort()
+        pct = lambda q: lap[min(len(lap) - 1, int(round(q * (len(lap) - 1))))]
         gather_ms = None
         if args.scaling == "strong" and dist is not None:        # the collective alone, HIP-event free (host clock, synchronous)
             runner.sync()
@@ -472,7 +495,7 @@ def main():
             shape_txt = (f"gliclass-{args.config} (DeBERTa-v3 shape L={cfg.layers} H={cfg.hidden})" if cfg.backbone != 1 else
                          f"gliclass-{args.config} (decoder backbone L={cfg.layers} H={cfg.hidden}, {cfg.heads}q/{cfg.kv_heads}kv x {cfg.head_dim})")
             out = {
-                "metric": "sequences/sec at batch=64 seq=1024, gliclass-base; %MFMA-peak",
+                "metric": f"sequences/sec at batch={args.batch} seq={S}, gliclass-{args.config}; %MFMA-peak",
                 "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                 "dtype": args.dtype, "mode": mode_txt, "data": "synthetic",
@@ -481,8 +504,14 @@ def main():
                            "parallelism": (f"batch-shard x{world}: one process per GPU, every rank a full batch, no data-path collective" if args.scaling == "weak" else
                                            f"batch-shard x{world}: one global batch split contiguously ({B} rows on rank 0), logits all-gathered to rank 0 every step (RCCL)")},
                 "hip_event_ms_per_step": round(ev_ms, 3),
+                "step_ms_median": round(pct(0.5), 3), "step_ms_p10": round(pct(0.1), 3), "step_ms_p90": round(pct(0.9), 3), "step_ms_samples": len(lap),
                 "finite": bool(np.isfinite(logits).all()),
             }
+            if world > 1 and scaling_defaulted:
+                out["config"]["parallelism"] += ("; BASELINE.json's c4 (one global batch of 256 split 32 per GPU, logits gathered) is "
+                                                 "`bench.py --config c4 --gpus N` (= --config large --batch 256 --scaling strong)")
+            if args.dump_logits:
+                np.save(args.dump_logits, logits)
             if host_ms is not None:
                 out["host_buffer_ms_per_step"] = round(host_ms, 3)     # H2D of ids/mask + forward + D2H of logits (glc_engine_forward)
             if gather_ms is not None:
@@ -493,6 +522,8 @@ def main():
                 out["cpu_baseline"] = cpu
                 out["parity_ok"] = bool(cpu["gpu_vs_cpu_max_prob_err"] <= BAR)
                 out["parity_bar"] = BAR
+            else:
+                out["parity_ok"] = None           # the oracle leg was skipped (--cpu-seqs 0 or N > 1): this line carries no parity evidence
             tdt = args.throughput_dtype
             if cpu and world == 1 and tdt != "none" and tdt != args.dtype:
                 # The opt-in 16-bit throughput mode on the same workload: reported beside the headline number, never instead of

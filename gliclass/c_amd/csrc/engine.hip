@@ -80,6 +80,7 @@ struct glc_engine {
     float2 *statsA = nullptr, *statsB = nullptr, *ln_part = nullptr;     // (mean, rstd) per row of X / H1 when they hold raw sums; the producers' partials
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
+    int range_retries = 0;          // host-buffer forwards repeated with the norms unfused because the folded one came out non-finite
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -468,7 +469,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     e->last_gs = gs;
     // 16-bit modes: the same LayerNorm fold on plain rows of T, when all four projections of a layer run on the staggered 256-tile kernel
     bool fold16 = false;
-    if (dt != GLC_F32 && e->ln_fused && prune && !e->keep_hidden && e->attn_impl != 1 && H % 256 == 0 && I % 256 == 0 && glc_gemm_use_stagger() && e->statsA && e->statsB && e->ln_part) {
+    if (dt != GLC_F32 && e->ln_fused && prune && !e->keep_hidden && e->attn_impl != 1 && H % 256 == 0 && I % 256 == 0 && e->statsA && e->statsB && e->ln_part) {
         GemmArgs t; t.Mpad = Mpad; t.N = H; t.K = H;
         fold16 = glc_gemm256_supported(dt, t) && !glc_gemm_small_m(t);
     }
@@ -625,7 +626,7 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
         // SwiGLU in the epilogue of the staggered 256-tile GEMM when the shapes allow it (16-bit operands)
         // (fp32 mode: the group-split 256-tile GEMM has the same epilogue; its small-forward fallback un-fuses on the interleaved columns)
         e->fused_swiglu = (e->dtype != GLC_F32 || (e->w_presplit && e->dec_split && H % 256 == 0)) && (2 * I) % 256 == 0 && H % 32 == 0 && I % 16 == 0 &&
-                          glc_gemm_use_stagger() && getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
+                          getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
         std::vector<float> bqkv(NQKV), gu_host(e->fused_swiglu ? 2 * (size_t)I * H : 0), fold_host;
         bool lok = true;
         for (int l = 0; l < L && lok; ++l) {
@@ -697,6 +698,13 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
     } while (0);
     (void)hipFree(staging);
     return ok;
+}
+
+// the value a 16-bit MFMA operand carries for f (host side of glc_launch_convert)
+inline float round_as_operand(float f, int dtype) {
+    if (dtype == GLC_F16) return (float)(_Float16)f;
+    if (dtype == GLC_BF16) return (float)(__bf16)f;
+    return f;
 }
 
 bool check_shape(const glc_engine* e, int B, int S, int C) {
@@ -868,7 +876,9 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                         double cs = 0.0, ds = 0.0;
                         const float* wr = Wsrc + (size_t)n * H;
                         float* o = wf.data() + (size_t)(row0 + n) * H;
-                        for (int k = 0; k < H; ++k) { const float f = wr[k] * gam[k]; o[k] = f; cs += (double)f; ds += (double)bet[k] * (double)wr[k]; }
+                        // c[n] sums the folded weights AS THE MFMA SEES THEM (rounded to T in the 16-bit modes; hi + lo in the fp32 mode is f to 2^-22):
+                        // summed from the unrounded values, rstd (acc - mean c[n]) would keep a residue mean rstd sum(round(W') - W')
+                        for (int k = 0; k < H; ++k) { const float f = wr[k] * gam[k]; o[k] = f; cs += (double)round_as_operand(f, dtype); ds += (double)bet[k] * (double)wr[k]; }
                         cv[row0 + n] = (float)cs; dv[row0 + n] = (float)(ds + (double)b0[row0 + n]);
                     }
                 };
@@ -929,14 +939,26 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
     const size_t nb = (size_t)B * S * sizeof(int64_t);
     HIPCHK(hipMemcpyAsync(e->d_ids, ids, nb, hipMemcpyHostToDevice, e->stream), -1);
     HIPCHK(hipMemcpyAsync(e->d_mask, mask, nb, hipMemcpyHostToDevice, e->stream), -1);
-    if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) return -1;
-    HIPCHK(hipMemcpyAsync(cnt, e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
-    if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
-    HIPCHK(hipStreamSynchronize(e->stream), -1);
-    if (e->profile) prof_collect(e);
     // Every matrix product runs on f16 / bf16 MFMA operands (the fp32 mode as split-f16 pairs), so an activation beyond the operand
     // range (|x| > 65504 for f16) turns into inf / NaN silently.  A result the reference's fp32 graph would not produce must not be
-    // returned as if it were one: fail the call.  (fp32 mode: GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native run the fp32 MFMAs.)
+    // returned as if it were one.  With the norm folded into the GEMMs the RAW residual stream is such an operand — a
+    // pre-norm decoder's massive-activation channels can leave the f16 range although every normalised row is tiny — so a non-finite
+    // result of a folded forward is retried ONCE with the norms as kernels of their own (residual stream plain fp32, only normalised
+    // rows split); what is still non-finite then fails the call.  (fp32 mode: GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native run the fp32 MFMAs.)
+    const bool fused_saved = e->ln_fused;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) { e->ln_fused = fused_saved; return -1; }
+        HIPCHK(hipMemcpyAsync(cnt, e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
+        if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
+        HIPCHK(hipStreamSynchronize(e->stream), -1);
+        if (e->profile) prof_collect(e);
+        bool finite = true;
+        for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n && finite; ++i) finite = isfinite(logits[i]);
+        if (finite || attempt == 1 || !(e->dtype == GLC_F32 && e->last_lnf)) break;
+        e->ln_fused = false;                // retry: norms unfused
+        e->range_retries++;
+    }
+    e->ln_fused = fused_saved;
     for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n; ++i)
         if (!isfinite(logits[i])) {
             set_err("forward: non-finite logit (row " + std::to_string(i / c_alloc) + "): an activation left the range of the " +
@@ -1070,6 +1092,7 @@ int glc_plan_length_buckets(const int* lengths, int B, int max_groups, int hidde
 }
 
 int glc_debug_last_forward_groups(const glc_engine* e) { return e ? e->last_groups : -1; }
+int glc_debug_range_retries(const glc_engine* e) { return e ? e->range_retries : -1; }
 
 int glc_engine_set_length_buckets(glc_engine* e, int max_groups) {
     if (!e || max_groups < 1 || max_groups > 64) { set_err("set_length_buckets: 1..64 groups"); return -1; }
@@ -1236,7 +1259,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K; g.mx_ws = mx_ws;
         if (mxb && which_in >= 100) g.prio_mode = which_in / 100 - 1;      // which = 100 (1 + prio) + 9 | 10
         const char* m = nullptr;
-        auto launch = [&]() -> const char* { return mxb ? glc_launch_gemm256x(e->stream, epi, g) : gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 5 || which == 7) ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : (which == 3 || which == 4) ? glc_launch_gemm256(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
+        auto launch = [&]() -> const char* { return mxb ? glc_launch_gemm256x(e->stream, epi, g) : gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 5 || which == 7) ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
         if (m) { set_err(m); break; }
         if (hipEventRecord(e->t0, e->stream)) break;
@@ -1268,24 +1291,6 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
                     for (size_t i = 0; i < 64 * 8; ++i) { pro += (double)hs[64 * 8 * 12 + 2 * i]; epi += (double)hs[64 * 8 * 12 + 2 * i + 1]; }
                     fprintf(stderr, "[gemm256s stamps] per tile and wave: entry -> loop %.0f cycles, loop end -> stores retired %.0f cycles\n", pro / (64 * 8), epi / (64 * 8));
                 } else if (dm) fprintf(stderr, "[gemm256s stamps] %s\n", dm);
-                (void)hipFree(dbuf);
-            }
-        }
-        if (which == 4) {     // diagnostic: one stamped launch of the 256-tile kernel; prints per-K-tile segment cycles (s_memtime ticks)
-            unsigned long long* dbuf = nullptr;
-            if (hipMalloc((void**)&dbuf, 64 * 8 * 4 * sizeof(unsigned long long)) == hipSuccess) {
-                (void)hipMemsetAsync(dbuf, 0, 64 * 8 * 4 * sizeof(unsigned long long), e->stream);
-                GemmArgs gs = g; gs.stamps = dbuf;
-                glc_launch_gemm256(e->stream, e->dtype, epi, gs);
-                (void)hipStreamSynchronize(e->stream);
-                std::vector<unsigned long long> hs(64 * 8 * 4);
-                if (hipMemcpy(hs.data(), dbuf, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                    double s[4] = {0, 0, 0, 0};
-                    for (int i = 0; i < 64 * 8; ++i) for (int k = 0; k < 4; ++k) s[k] += (double)hs[i * 4 + k];
-                    const double nkt = K / 64.0, n = 64 * 8;
-                    fprintf(stderr, "[stamps M=%d N=%d K=%d] per K-tile per wave (shader cycles): compute %.0f  dma_wait %.0f  barrier %.0f | whole tile %.0f cycles\n",
-                            M, N, K, s[0] / n / nkt, s[1] / n / nkt, s[2] / n / nkt, s[3] / n);
-                }
                 (void)hipFree(dbuf);
             }
         }

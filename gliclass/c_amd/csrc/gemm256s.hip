@@ -1,7 +1,8 @@
-// 256x256 MFMA GEMM, STAGGERED variant of gemm256.hip (same operand contract, tile, epilogues, accumulation order —
-// outputs are bit-identical to gemm256, which scripts/race_screen.py uses as a race detector).
+// 256x256 MFMA GEMM with temporally staggered wave groups.  (Its lock-step predecessor gemm256.hip — 2 x 64 KiB stages, every wave
+// loading and multiplying in step — was removed in round 3; the two main loops of THIS file, half-line and full-line stages, keep the
+// same accumulation order and give bit-identical outputs, which scripts/race_screen.py uses as a race detector.)
 //
-// Stamps in gemm256's main loop showed, per 64-deep K-tile and wave, ~2440 cycles in the load+MFMA segment (floor 2048:
+// Stamps in the lock-step main loop showed, per 64-deep K-tile and wave, ~2440 cycles in the load+MFMA segment (floor 2048:
 // two waves share one SIMD's matrix pipe) plus ~800 cycles at s_waitcnt/s_barrier where the pipe idles: the two waves
 // of a SIMD execute [loads ... MFMAs ... wait] in lockstep, so nothing covers the load and wait parts.  Here:
 //   * K is consumed in 32-deep steps on a 4-slot LDS ring (32 KiB per slot), DMA issued three steps ahead, counted
@@ -780,7 +781,6 @@ bool glc_gemm_small_m(const GemmArgs& a) {
     return (long long)(a.Mpad / TM) * (a.N / TN) * 2 < ncu;
 }
 
-bool glc_gemm_use_stagger() {
-    static const bool on = getenv("GLC_GEMM_STAGGER") == nullptr || atoi(getenv("GLC_GEMM_STAGGER")) != 0;   // default on; GLC_GEMM_STAGGER=0 -> gemm256.hip
-    return on;
+bool glc_gemm256_supported(int dtype, const GemmArgs& a) {
+    return (dtype == GLC_DT_BF16 || dtype == GLC_DT_F16) && a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 64 == 0;
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
 }
 
-template <int EPI, bool VMODE, bool DIAG = false>
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -125,6 +125,12 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
 
     f16x8 a16[4][2], w16[2][2];
     i32x8 xa[4], xw[2];
+    if constexpr (ABL == 4) {      // (timing-only build without fragment reads: defined operands)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a16[i][0] = a16[i][1] = (f16x8)(f16_t)(0.001f * lane); xa[i] = (i32x8)(0x38383838 + lane); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { w16[j][0] = w16[j][1] = (f16x8)(f16_t)(0.002f * lane); xw[j] = (i32x8)(0x38383838 - lane); }
+    }
     const int pm = p.prio_mode;               // 0: no priorities; 1: MFMA phase at priority 1; 2: load phase at priority 2; 3: the late wave group at priority 1 throughout
     if (pm == 3 && wm == 1) __builtin_amdgcn_s_setprio(1);
     stage_fl(0);
@@ -142,12 +148,13 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
         // ---- phase A ----
         stamp(-1);
         if (pm == 2) __builtin_amdgcn_s_setprio(2);
-        if (!odd && s + 1 < ng) stage_fl(s + 1);
+        if (!odd && s + 1 < ng && ABL != 5) stage_fl(s + 1);      // (ABL 4 / 5 / 6: timing-only builds — no fragment reads / no DMA / no MFMAs; wrong results)
         stamp(5 * odd + 0);
         {
             const unsigned char* sa = smem256x + ((2 * s) & (NSLOT - 1)) * STAGE + arow;
             const unsigned char* sw = smem256x + ((2 * s + 1) & (NSLOT - 1)) * STAGE + wrow;
-            if (!odd) {
+            if constexpr (ABL == 4) {
+            } else if (!odd) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     w16[j][0] = *reinterpret_cast<const f16x8*>(sw + j * 32 * LINE + ck0);
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
         stamp(5 * odd + 2);
         // ---- phase B ----
         if (pm == 1) __builtin_amdgcn_s_setprio(1);
-        if (!odd) {
+        if constexpr (ABL == 6) {
+        } else if (!odd) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -405,17 +413,22 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
     }
 }
 
-template <int EPI, bool VMODE, bool DIAG = false> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
-    if constexpr (!DIAG && EPI == EPI_BIAS && !VMODE) { if (a.stamps) return launch_x<EPI, VMODE, true>(st, a, n_tile0, ntn); }
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+    if constexpr (!DIAG && ABL == 0 && EPI == EPI_BIAS && !VMODE) {
+        if (a.prio_mode == 4) return a.stamps ? launch_x<EPI, VMODE, true, 4>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 4>(st, a, n_tile0, ntn);
+        if (a.prio_mode == 5) return a.stamps ? launch_x<EPI, VMODE, true, 5>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 5>(st, a, n_tile0, ntn);
+        if (a.prio_mode == 6) return a.stamps ? launch_x<EPI, VMODE, true, 6>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 6>(st, a, n_tile0, ntn);
+        if (a.stamps) return launch_x<EPI, VMODE, true>(st, a, n_tile0, ntn);
+    }
     static std::atomic<unsigned> lds_ok{0};
-    if (!glc_raise_lds_limit(gemm256x_kernel<EPI, VMODE, DIAG>, NSLOT * STAGE, lds_ok)) return "gemm256x: cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(gemm256x_kernel<EPI, VMODE, DIAG, ABL>, NSLOT * STAGE, lds_ok)) return "gemm256x: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
     GemmArgs b = a;
     b.n_group = 0;
     static const int prio_env = getenv("GLC_GEMM_PRIO") ? atoi(getenv("GLC_GEMM_PRIO")) : 1;      // developer A/B switch
     b.prio_mode = a.prio_mode >= 0 ? a.prio_mode : prio_env;
     if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);      // wide N: as gemm256s.hip
-    hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE, DIAG>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
+    hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE, DIAG, ABL>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
     return nullptr;
 }
 

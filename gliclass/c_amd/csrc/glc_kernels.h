@@ -21,8 +21,7 @@ struct GemmArgs {
     int Mpad = 0, N = 0, K = 0;
     int Mvalid = 0, Sp = 0, nh = 0, H = 0;  // QKV only
     const void* W2 = nullptr; const float* bias2 = nullptr; int m_split = 0;   // gemm_nt (128-tile): rows >= m_split use W2 / bias2 (two-group GEMM)
-    unsigned long long* stamps = nullptr;   // gemm256 diagnostic build only: per (block<64, wave) cycle sums [compute, dma_wait, barrier_wait, total]
-    int spread_dma = 0;                     // gemm256: issue the next stage's DMA between MFMA groups instead of up front
+    unsigned long long* stamps = nullptr;   // gemm256s / gemm256x diagnostic builds only: per (block < 64, wave) cycle sums of the main-loop phases
     int qkv_skip_q = 0;                     // QKV: produce only K and V^T (pruned last layer)
     int w_presplit = 0;                     // gemm_nt split-f16 path (T = float): W already holds [32 hi halves | 32 lo halves] per 32-k group (glc_launch_presplit)
     int qkv_split = 0;                      // QKV, T = float: write Q / K / V^T units as [8 hi halves | 8 lo halves] (split-f16 attention, glc_common.h f16x8s)
@@ -61,10 +60,8 @@ const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, 
 // decoder backbone: plain fp32 rows -> raw group-split rows + RMSNorm statistics (0, rstd) per row
 const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H);
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
-bool glc_gemm256_supported(int dtype, const GemmArgs& a);
-const char* glc_launch_gemm256(hipStream_t st, int dtype, int epi, const GemmArgs& a);    // 256x256 tile, 16-bit T
+bool glc_gemm256_supported(int dtype, const GemmArgs& a);                                 // shapes the 256x256 LDS-DMA kernel takes (16-bit T)
 const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmArgs& a);   // 256x256 tile, staggered wave groups (gemm256s.hip)
-bool glc_gemm_use_stagger();
 void glc_gemm_set_full_lines(int on);       // gemm256s.hip: full-line (operand-major) ring stages on / off, process-wide (developer A/B; default on, GLC_GEMM_FL=0)
 bool glc_gemm_small_m(const GemmArgs& a);   // gemm256s.hip: too few 256x256 tiles for this device -> use the 128x128 kernel
 // picks the 256x256 LDS-DMA kernel when the shape allows it, else the 128x128 one
@@ -74,7 +71,7 @@ inline const char* glc_launch_gemm_auto(hipStream_t st, int dtype, int epi, cons
     // Small M (the reference's own batches of 8 short texts): too few 256x256 tiles to cover the CUs, and each tile runs its
     // whole K loop alone — the 128x128 kernel gives 4x the workgroups.  Threshold: fewer 256-tiles than half the CUs.
     if (glc_gemm_small_m(a)) return glc_launch_gemm(st, dtype, epi, a);
-    return glc_gemm_use_stagger() ? glc_launch_gemm256s(st, dtype, epi, a) : glc_launch_gemm256(st, dtype, epi, a);
+    return glc_launch_gemm256s(st, dtype, epi, a);
 }
 
 // Row LayerNorm: Y[m,:] = LN(X[m,:]) * gamma + beta, rows [0, M).  X, Y element type T.

@@ -116,6 +116,10 @@ class Engine:
         if self.L.glc_debug_set_precision_mask(self.h, int(mask)) != 0:
             raise self._err("glc_debug_set_precision_mask")
 
+    def range_retries(self):
+        """host-buffer forwards repeated with the norms unfused because the folded forward came out non-finite"""
+        return int(self.L.glc_debug_range_retries(self.h))
+
     def keep_hidden(self, on=True):
         self.L.glc_debug_keep_hidden(self.h, int(on))
 

@@ -142,6 +142,9 @@ int glc_debug_last_forward_ln_folded(const glc_engine* e);      /* 1: the last f
  * pipeline to f16 by dropping its lo halves — numerically the cheaper kernel that never fetches them.  Bits 0-7: (A, W) of the QKV,
  * attention-output, FFN1, FFN2 projections; 8-13: attention Q, K, V^T, P, PQ rows, PK rows; 14: the residual rows. */
 int glc_debug_set_precision_mask(glc_engine* e, int mask);
+/* Host-buffer forwards that were repeated with the norms unfused because the folded forward came out non-finite (a raw residual
+ * stream beyond the f16 operand range; engine.hip forward_one). */
+int glc_debug_range_retries(const glc_engine* e);
 /* 256-tile GEMM ring: full-line (operand-major) stages on / off, process-wide developer A/B switch; bit-identical results. */
 int glc_debug_set_gemm_full_lines(int on);
 

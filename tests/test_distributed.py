@@ -131,3 +131,11 @@ def test_bench_without_gpus_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+def test_bench_c4_alias_is_the_strong_batch_shard():
+    """`bench.py --config c4 --gpus N` = BASELINE.json configs[3] as one flag: gliclass-large, ONE global batch of 256 split over the
+    ranks (32 per GPU at N = 8), logits gathered to rank 0 (the reference's batch loop, /root/reference/main.c:141-150, as a shard)."""
+    out = _run_bench_stub("--gpus", "2", "--config", "c4", "--labels", "2", "--steps", "2", "--warmup", "1")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["global_batch"] == 256 and out["rows_rank0"] == 128
+    assert out["gathered_rows"] == list(range(256))

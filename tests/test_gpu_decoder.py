@@ -255,3 +255,32 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
                 assert not np.array_equal(gs, unf), "the RMSNorm switch changed nothing: is the folded path running?"
     finally:
         eng.close()
+
+
+def test_decoder_massive_activation_channel_falls_back_to_unfused_norms(weights_for):
+    """with RMSNorm folded into the GEMMs the RAW residual stream is a split-f16 GEMM operand.  A pre-norm decoder
+    whose residual stream carries a massive-activation channel (|x| > 65504: beyond f16, although every normalised row is tiny)
+    makes that forward non-finite; the engine must then repeat it once with the norms as kernels of their own (plain fp32 residual
+    stream, only normalised rows split) and return what the fp32 reference returns."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w0 = weights_for("dec-mini")
+    w = dict(w0)
+    emb = w0["embed_tokens.weight"].copy()
+    emb[:, 5] *= 2.0e5                         # one channel of the embedding rows ~ 1e5: the residual stream leaves the f16 range
+    w["embed_tokens.weight"] = emb
+    ids, mask, _ = synth.make_inputs(cfg, 3, 200, 3, seed=91, ragged=True)
+    ref = oracle_c.forward(cfg, w, ids, mask)
+    assert np.isfinite(ref).all()
+    eng = Engine(cfg, w, dtype="f32")
+    try:
+        eng.set_group_split(2)
+        got = eng.forward(ids, mask)
+        assert eng.last_group_split()
+        assert np.isfinite(got).all()
+        if cfg.hidden % 256 == 0:
+            assert eng.range_retries() == 1, "the folded forward should have overflowed and been repeated"
+        assert np.abs(sig(got) - sig(ref)).max() <= 1e-3
+    finally:
+        eng.close()

@@ -1,5 +1,6 @@
 """GPU (-m gpu): BASELINE.json's configs at their FULL sizes, through the C-ABI.
 
+  c2  gliclass-small  B=8   S=512    (BASELINE.json configs[1]: the first GPU config, fp32, vs CPU probabilities)
   c3  gliclass-base   B=64  S=1024   (the headline bench shape: the 256x256 staggered GEMM instantiations and the band attention
                                       kernel the bench runs, which smaller batches never dispatch to)
   c4  gliclass-large  B=32  S=1024   (one GPU's shard of the 8-GPU batch of 256)
@@ -39,6 +40,27 @@ def _check_rows_vs_oracle(cfg, w, ids, mask, got, rows, tol):
     err = float(np.abs(sig(got[rows]) - sig(ref)).max())
     assert err <= tol, (rows, err)
     return err
+
+
+def test_c2_small_b8_s512(c_generated_weights):
+    """BASELINE.json configs[1] at its exact shape: gliclass-small, batch 8, seq 512, fp32 (the default mode) — all 8 rows vs the oracle."""
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    cfg = CONFIGS["small"]
+    spec = "synthetic:small:42"
+    w = c_generated_weights(spec, cfg)
+    B, S, Cn = 8, 512, 8
+    ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=1234)
+    eng = Engine.from_spec(cfg, spec, dtype="f32")
+    try:
+        eng.set_length_buckets(1)
+        got = eng.forward(ids, mask)
+        assert got.shape == (B, Cn) and np.isfinite(got).all()
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, list(range(B)), TOL_DEFAULT_MODE)
+        print(f"c2 f32: max |prob - oracle| on all 8 rows = {err:.2e} (bar {BAR})")
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])

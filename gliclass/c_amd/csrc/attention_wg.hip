@@ -510,6 +510,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     if constexpr (sizeof(T) == 2) {
         store_acc32_wide<T>(o0, inv, reinterpret_cast<T*>(outp), h);
         store_acc32_wide<T>(o1, inv, reinterpret_cast<T*>(outp) + 32, h);
+    } else if (a.ctx_gs == 2) {
+        // GX context rows (glc_common.h: the A operand of the MX cross-term GEMM): per 32 columns [32 hi | 32 lo8 | 32 hi8].  Lane c
+        // (h = 0) gets the 8 consecutive columns 16 p .. 16 p + 7 of its query row, lane c + 32 the columns 16 p + 8 .. 16 p + 15: each
+        // lane keeps one of its two register groups and receives the matching group of its partner lane (one cross-half exchange per
+        // register).  (v_permlane32_swap through its builtin lost its second result here — hipcc, ROCm 7.2, stored the first one twice;
+        // the shuffle form is the one that compiled correctly.)
+        unsigned char* row = reinterpret_cast<unsigned char*>(a.CTX) + ((size_t)b * Sp + q0 + c) * 4 * a.H;
+        auto store_gx = [&](const f32x16& o, int col0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float own_a = o[8 * p + e] * inv, own_b = o[8 * p + 4 + e] * inv;      // group 2p (columns 16p + 4h + e), group 2p + 1 (+ 8)
+                    const float got = __shfl_xor(h ? own_a : own_b, 32, 64);                      // h = 0: the partner's group 2p; h = 1: the partner's group 2p + 1
+                    v[e] = h ? got : own_a;           // h = 0: columns 16p + e (own), 16p + 4 + e (partner);  h = 1: 16p + 8 + e (partner), 16p + 12 + e (own)
+                    v[4 + e] = h ? own_b : got;
+                }
+                gx_store8(row, col0 + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT));
+            }
+        };
+        store_gx(o0, 64 * hh);
+        store_gx(o1, 64 * hh + 32);
     } else if (a.ctx_gs) {
         // group-split context rows (glc_kernels.h): the head's 64 columns are groups 2 hh (o0) and 2 hh + 1 (o1) of the row's
         // [32 hi halves | 32 lo halves] groups; hi = f16(v), lo = f16(v - hi), 16-byte stores through the 16-bit store helper

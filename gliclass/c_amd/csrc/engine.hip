@@ -61,6 +61,9 @@ struct LayerW {
     // as group-split rows, their row sums c and the folded biases d = W beta + b
     void *W1f = nullptr, *Wqkvf = nullptr;
     float *c1 = nullptr, *d1 = nullptr, *cq = nullptr, *dq = nullptr;
+    // MX pipeline (glc_engine::mx): the projection weights once more as GX rows (glc_common.h) with their fp8 exponents
+    void *Wqkv_x = nullptr, *Wqkvf_x = nullptr, *Wo_x = nullptr, *W1f_x = nullptr, *W2_x = nullptr;
+    int ws_qkv = 0, ws_qkvf = 0, ws_o = 0, ws_1f = 0, ws_2 = 0;
 };
 
 }  // namespace
@@ -72,6 +75,9 @@ struct glc_engine {
     bool w_presplit = false;        // weights of the split-f16 fp32 GEMMs are split once at load (encoder layers in fp32 mode; head projectors in every mode)
     bool dec_split = false;         // decoder backbone, fp32 mode: RoPE/layout pass writes split-f16 units, grouped-query attention on three-MFMA products
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
+    bool mx_built = false, mx = false;   // MX cross-term projections (gemm256x.hip) on GX rows: weights present / pipeline selected (GLICLASS_MX, glc_debug_set_mx)
+    bool last_mx = false;                // the last forward ran the MX pipeline
+    int debug_stop = -1;                 // developer: leave run_forward after stage (10 * layer + k), k = 0 QKV, 1 attention, 2 attn-out, 3 FFN1, 4 FFN2 (+ LayerNorm): workspace inspection
     int prec_mask = 0;              // precision-budget switches (PM_* of glc_kernels.h; glc_debug_set_precision_mask): operands rounded to f16 in the group-split pipeline
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
     bool last_gs = false;           // the last forward ran the group-split pipeline
@@ -467,6 +473,12 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         gs = e->gs_mode == 2 || !glc_gemm_small_m(t);
     }
     e->last_gs = gs;
+    // MX pipeline (round 3): the group-split pipeline with GX rows and the MX cross-term GEMM (gemm256x.hip) for every projection of the
+    // full layers — a_hi*w_hi as f16 MFMAs, both cross terms as one block-scaled fp8 MFMA.  Needs the LayerNorm fold on every layer.
+    bool mx = gs && e->mx && e->mx_built && e->ln_fused && e->prec_mask == 0 && c.layers >= 2;
+    for (int l = 0; mx && l < c.layers; ++l) mx = e->layers[l].W1f_x && e->layers[l].Wqkv_x && e->layers[l].Wo_x && e->layers[l].W2_x && (l == 0 || e->layers[l].Wqkvf_x);
+    e->last_mx = mx;
+    auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* { return mx ? glc_launch_gemm256x(st, epi, ga) : glc_launch_gemm256s_gs(st, epi, ga); };
     // 16-bit modes: the same LayerNorm fold on plain rows of T, when all four projections of a layer run on the staggered 256-tile kernel
     bool fold16 = false;
     if (dt != GLC_F32 && e->ln_fused && prune && !e->keep_hidden && e->attn_impl != 1 && H % 256 == 0 && I % 256 == 0 && e->statsA && e->statsB && e->ln_part) {
@@ -474,7 +486,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         fold16 = glc_gemm256_supported(dt, t) && !glc_gemm_small_m(t);
     }
     { Prof p(e, PC_EMBED);
-      if (gs) KCHK(glc_launch_embed_gs(st, ids, mask, (const float*)e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false);
+      if (gs) KCHK(glc_launch_embed_gs(st, ids, mask, (const float*)e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id, mx ? 1 : 0), false);
       else KCHK(glc_launch_embed(st, dt, ids, mask, e->emb, e->eln_g, e->eln_b, c.ln_eps, e->X, e->kbias, B, S, Sp, H, c.vocab, c.pad_id), false); }
     if (e->keep_hidden) HIPCHK(hipMemcpyAsync(e->hidden_dump, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
 
@@ -493,29 +505,36 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit;
         if (last) break;
         if (x_raw) { g.W = w.Wqkvf; g.bias = w.dq; g.a_stats = e->statsA; g.ln_c = w.cq; }
+        if (mx) { g.W = x_raw ? w.Wqkvf_x : w.Wqkv_x; g.mx_ws = x_raw ? w.ws_qkvf : w.ws_qkv; }
         const int pm = gs ? e->prec_mask : 0;
         g.prec = pm & 3;
-        { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
+        { Prof p(e, PC_QKV); KCHK(gs ? gemm_gs(EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
+        if (e->debug_stop == 10 * l + 0) return true;
         AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-        a.split = asplit; a.ctx_gs = gs; a.prec = (pm >> 8) & 63;
+        a.split = asplit; a.ctx_gs = mx ? 2 : (gs ? 1 : 0); a.prec = (pm >> 8) & 63;
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
         { Prof p(e, PC_ATTN); KCHK(launch_band(a), false); }
+        if (e->debug_stop == 10 * l + 1) return true;
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
         if (x_raw) { const LayerW& wp = e->layers[l - 1]; o.r_stats = e->statsA; o.r_gamma = wp.ln2g; o.r_beta = wp.ln2b; }
         if (lnf) { o.C = e->H1; o.ln_part = e->ln_part; }      // raw sum -> H1 (group-split rows) + partials
         o.prec = ((pm >> 2) & 3) | ((pm & PM_RESID) ? 4 : 0);
-        { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
+        if (mx) { o.W = w.Wo_x; o.mx_ws = w.ws_o; }
+        { Prof p(e, PC_ATTN_OUT); KCHK(gs ? gemm_gs(EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }
         { Prof p(e, PC_LN); KCHK(lnf ? glc_launch_ln_stats(st, e->ln_part, H / 64, e->statsB, M, H, c.ln_eps)
                                  : gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H)
                                       : glc_launch_layernorm(st, dt, e->T1, e->H1, w.ln1g, w.ln1b, c.ln_eps, M, H), false); }
+        if (e->debug_stop == 10 * l + 2) return true;
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.W1; f1.bias = w.b1; f1.C = e->FF; f1.Mpad = Mpad; f1.N = I; f1.K = H;
         if (lnf) { f1.W = w.W1f; f1.bias = w.d1; f1.a_stats = e->statsB; f1.ln_c = w.c1; }
         f1.prec = (pm >> 4) & 3;
-        { Prof p(e, PC_FFN1); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
+        if (mx) { f1.W = w.W1f_x; f1.mx_ws = w.ws_1f; }
+        { Prof p(e, PC_FFN1); KCHK(gs ? gemm_gs(EPI_GELU, f1) : launch_gemm_auto(e, dt, EPI_GELU, f1), false); }
+        if (e->debug_stop == 10 * l + 3) return true;
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.W2; f2.bias = w.b2; f2.C = e->T1; f2.resid = e->H1; f2.Mpad = Mpad; f2.N = H; f2.K = I;
         if (lnf) { f2.r_stats = e->statsB; f2.r_gamma = w.ln1g; f2.r_beta = w.ln1b; }
@@ -523,11 +542,13 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         // the next consumer of X takes raw rows only if it is a folded QKV of the pipeline (not the pruned last layer, which gathers normalised rows)
         const bool next_raw = lnf && l + 1 < c.layers && e->layers[l + 1].Wqkvf && !(prune && l + 1 == c.layers - 1);
         if (next_raw) { f2.C = e->X; f2.ln_part = e->ln_part; }
-        { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
+        if (mx) { f2.W = w.W2_x; f2.mx_ws = w.ws_2; }
+        { Prof p(e, PC_FFN2); KCHK(gs ? gemm_gs(EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         { Prof p(e, PC_LN); KCHK(next_raw ? glc_launch_ln_stats(st, e->ln_part, H / 64, e->statsA, M, H, c.ln_eps)
-                                 : gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H)
+                                 : gs ? glc_launch_layernorm_gs(st, (const float*)e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H, mx ? 1 : 0)
                                       : glc_launch_layernorm(st, dt, e->T1, e->X, w.ln2g, w.ln2b, c.ln_eps, M, H), false); }
         x_is_raw = next_raw;
+        if (e->debug_stop == 10 * l + 4) return true;
         if (e->keep_hidden)
             HIPCHK(hipMemcpyAsync((char*)e->hidden_dump + (size_t)(l + 1) * M * H * es, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
     }
@@ -545,11 +566,12 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit && band_sel;
         if (band_sel) HIPCHK(hipMemsetAsync(e->tile_flag, 0, (size_t)Mpad >> 5, st), false);
         // (group-split pipeline: the compact rows leave it here — plain fp32, the rest of this layer runs on the small-M kernels)
-        if (gs) KCHK(glc_launch_gather_rows_gs(st, e->X, e->cls_pos, ccap, (float*)e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
+        if (gs) KCHK(glc_launch_gather_rows_gs(st, e->X, e->cls_pos, ccap, (float*)e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc, mx ? 1 : 0), false);
         else KCHK(glc_launch_gather_rows(st, dt, e->X, e->cls_pos, ccap, e->Xs, e->sel_b, e->sel_q, band_sel ? e->tile_flag : nullptr, B, Sp, H, Cc), false);
         if (gs) g.prec = e->prec_mask & 3;
+        if (mx) { g.W = w.Wqkv_x; g.mx_ws = w.ws_qkv; }
         if (band_sel) g.q_tile_flag = e->tile_flag;       // the gather has flagged the query tiles that hold selected rows: the Q third skips the others
-        KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false);
+        KCHK(gs ? gemm_gs(EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false);
         if (band_sel) {
             AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
             a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;
@@ -774,6 +796,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     if (const char* lv = getenv("GLC_LNF")) e->ln_fused = atoi(lv) != 0;      // developer A/B switch
+    // MX cross-term pipeline: GLICLASS_MX=1 builds the GX weight copies and selects it; GLICLASS_MX=build only builds them (glc_debug_set_mx)
+    if (const char* mv = getenv("GLICLASS_MX")) { e->mx_built = dtype == GLC_F32 && !dec && (atoi(mv) != 0 || !strcmp(mv, "build")); e->mx = e->mx_built && atoi(mv) != 0; }
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
@@ -902,6 +926,35 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                     if (!w.cq || !w.dq) { lok = false; break; }
                 }
                 if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // host vectors are reused
+            }
+            if (lok && e->mx_built) {
+                // MX pipeline: the projection weights once more as GX rows (hi f16 | lo8 | hi8, glc_common.h), each tensor with the fp8
+                // exponent its largest magnitude allows.  (The folded copies are re-derived here: the fold above has reused its host buffer.)
+                auto to_gx = [&](const float* src, size_t n, void*& dst, int& ws) -> bool {
+                    float mx = 0.f;
+                    for (size_t i = 0; i < n; ++i) { const float a = fabsf(src[i]); mx = a > mx ? a : mx; }
+                    ws = glc_gx_weight_exponent(mx);
+                    dst = dmalloc(e, n * sizeof(float), false);
+                    if (!dst || !upload_as(e, src, n, dst, staging)) return false;
+                    const char* pm = glc_launch_to_gx(e->stream, dst, n, ws, 1);
+                    if (pm) { set_err(pm); return false; }
+                    return hipStreamSynchronize(e->stream) == hipSuccess;
+                };
+                std::vector<float> xh((size_t)(I > 3 * H ? I : 3 * H) * H);
+                const size_t HH = (size_t)H * H;
+                memcpy(xh.data(), wq.data(), HH * sizeof(float)); memcpy(xh.data() + HH, t[2], HH * sizeof(float)); memcpy(xh.data() + 2 * HH, t[4], HH * sizeof(float));
+                lok = to_gx(xh.data(), 3 * HH, w.Wqkv_x, w.ws_qkv) && to_gx(t[6], HH, w.Wo_x, w.ws_o) && to_gx(t[12], (size_t)H * I, w.W2_x, w.ws_2);
+                if (lok) {
+                    for (int n = 0; n < I; ++n) for (int k = 0; k < H; ++k) xh[(size_t)n * H + k] = t[10][(size_t)n * H + k] * t[8][k];
+                    lok = to_gx(xh.data(), (size_t)I * H, w.W1f_x, w.ws_1f);
+                }
+                if (lok && l > 0) {
+                    const float* const* tp = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * (l - 1);
+                    const float* src3[3] = {wq.data(), t[2], t[4]};
+                    for (int q = 0; q < 3; ++q) for (size_t n = 0; n < (size_t)H; ++n) for (int k = 0; k < H; ++k) xh[(q * (size_t)H + n) * H + k] = src3[q][n * H + k] * tp[14][k];
+                    lok = to_gx(xh.data(), 3 * HH, w.Wqkvf_x, w.ws_qkvf);
+                }
+                if (!lok) break;
             }
         }
         if (!lok) { fail(); break; }
@@ -1177,6 +1230,48 @@ int glc_debug_set_group_split(glc_engine* e, int mode) {
     return 0;
 }
 int glc_debug_last_forward_group_split(const glc_engine* e) { return e ? (e->last_gs ? 1 : 0) : -1; }
+/* MX cross-term pipeline on / off (needs the GX weight copies: an engine created under GLICLASS_MX=1 or =build). */
+int glc_debug_set_mx(glc_engine* e, int on) {
+    if (!e) return -1;
+    if (on && !e->mx_built) { set_err("set_mx: this engine was created without the GX weight copies (GLICLASS_MX=1 or =build)"); return -1; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->mx = on != 0;
+    return 0;
+}
+int glc_debug_last_forward_mx(const glc_engine* e) { return e ? (e->last_mx ? 1 : 0) : -1; }
+/* Developer: stop the next forwards after stage 10 * layer + k (k = 0 QKV, 1 attention, 2 attention-output, 3 FFN1, 4 FFN2 + LayerNorm;
+ * -1 = run to the end; logits are garbage when stopped) and read workspace rows as fp32: which = 0 X, 1 H1, 2 CTX, 3 FF (row formats
+ * decoded: GX after an MX forward, GS after a group-split one), 4 T1 (plain fp32), 5 statsA, 6 statsB (2 floats per row). */
+int glc_debug_set_stop(glc_engine* e, int stage) { if (!e) return -1; e->debug_stop = stage; return 0; }
+int glc_debug_read_workspace(glc_engine* e, int which, int rows, float* out) {
+    if (!e || !out || rows <= 0 || which < 0 || which > 9) { set_err("read_workspace: bad args"); return -1; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(hipSetDevice(e->device), -1);
+    HIPCHK(hipStreamSynchronize(e->stream), -1);
+    if (rows > e->capM) { set_err("read_workspace: more rows than the workspace holds"); return -1; }
+    const int H = e->cfg.hidden, I = e->cfg.inter;
+    if (which >= 7) { HIPCHK(hipMemcpy(out, which == 7 ? e->Qh : which == 8 ? e->Kh : e->Vt, (size_t)rows * e->cfg.hidden * 4, hipMemcpyDeviceToHost), -1); return 0; }   // raw units
+    if (which >= 5) { HIPCHK(hipMemcpy(out, which == 5 ? e->statsA : e->statsB, (size_t)rows * 8, hipMemcpyDeviceToHost), -1); return 0; }
+    const void* src = which == 0 ? e->X : which == 1 ? e->H1 : which == 2 ? e->CTX : which == 3 ? e->FF : e->T1;
+    const int W = which == 3 ? I : H;
+    std::vector<unsigned char> raw((size_t)rows * W * 4);
+    HIPCHK(hipMemcpy(raw.data(), src, raw.size(), hipMemcpyDeviceToHost), -1);
+    if (which == 4 || !e->last_gs) { memcpy(out, raw.data(), raw.size()); return 0; }
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < W; ++c) {
+            const unsigned char* g = raw.data() + ((size_t)r * W + (c & ~31)) * 4;
+            _Float16 hi, lo; memcpy(&hi, g + 2 * (c & 31), 2);
+            float v = (float)hi;
+            if (e->last_mx) {
+                const unsigned char b = g[64 + 16 * ((c & 31) >> 3) + (c & 7)];
+                const int sg = b >> 7, ex = (b >> 3) & 15, mn = b & 7;
+                const float l8 = ex == 0 ? ldexpf((float)mn, -9) : ldexpf(1.0f + mn / 8.0f, ex - 7);
+                v += (sg ? -l8 : l8) * ldexpf(1.0f, -GLC_GX_SHIFT);
+            } else { memcpy(&lo, g + 64 + 2 * (c & 31), 2); v += (float)lo; }
+            out[(size_t)r * W + c] = v;
+        }
+    return 0;
+}
 /* Group-split pipeline with LayerNorm folded into the GEMMs (1, default) or as kernels of its own (0).  The folded weights are built
  * at load unless GLC_LNF=0 was set then; without them the switch has no effect. */
 int glc_debug_last_forward_ln_folded(const glc_engine* e) { return e ? (e->last_lnf ? 1 : 0) : -1; }
@@ -1250,7 +1345,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         if (gsb) {      // fp32 values, split in place into the group-split image (or the GX image)
             if (hipMemcpyAsync(A, tmp, nA * 4, hipMemcpyDeviceToDevice, e->stream) || hipMemcpyAsync(W, tmp, nW * 4, hipMemcpyDeviceToDevice, e->stream) ||
                 hipMemcpyAsync(R, tmp, nC * 4, hipMemcpyDeviceToDevice, e->stream)) { set_err("gemm_bench: copy failed"); break; }
-            if (mxb ? (glc_launch_to_gx(e->stream, A, nA, 0) || glc_launch_to_gx(e->stream, W, nW, mx_ws) || glc_launch_to_gx(e->stream, R, nC, 0))
+            if (mxb ? (glc_launch_to_gx(e->stream, A, nA, 0, 0) || glc_launch_to_gx(e->stream, W, nW, mx_ws, 1) || glc_launch_to_gx(e->stream, R, nC, 0, 0))
                     : (glc_launch_presplit(e->stream, A, nA) || glc_launch_presplit(e->stream, W, nW) || glc_launch_presplit(e->stream, R, nC))) { set_err("gemm_bench: split failed"); break; }
         } else
         if (glc_launch_convert(e->stream, e->dtype, tmp, A, nA) || glc_launch_convert(e->stream, e->dtype, tmp, W, nW) ||
@@ -1300,51 +1395,102 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
 }
 
 /* Developer check: the MX cross-term GEMM (gemm256x.hip) against the split-f16 GEMM (gemm256s.hip, GS) on the same random fp32 operands
- * (A ~ U(-a_amp, a_amp), W ~ U(-w_amp, w_amp), bias), EPI_BIAS with plain fp32 outputs.  out[0] = max |C_mx - C_gs|, out[1] = max |C_gs|,
- * out[2] = rms(C_mx - C_gs), out[3] = rms(C_gs).  Returns 0 or < 0. */
-int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, double* out) {
-    if (!e || !out || M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || K % 32) { set_err("gemm_mx_check: bad args"); return -1; }
+ * (A ~ U(-a_amp, a_amp), W ~ U(-w_amp, w_amp), bias), every epilogue path:
+ *   mode 0  EPI_BIAS, plain fp32 outputs                      mode 1  EPI_GELU with the LayerNorm fold (a_stats, ln_c), GX / GS row outputs
+ *   mode 2  EPI_RESID, raw residual rows + r_stats / gamma / beta, raw row outputs + ln_part          mode 3  EPI_RESID, plain fp32 out
+ *   mode 4  EPI_QKV with the fold (N = 3 H, Sp = 256): Q, K, V^T split-f16 units
+ * out[0] = max |mx - gs|, out[1] = max |gs|, out[2] = rms(mx - gs), out[3] = rms(gs) over the decoded outputs (mode 2: + the ln_part
+ * sums in out[4] = max |diff|).  Returns 0 or < 0. */
+int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, int mode, double* out) {
+    if (!e || !out || M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || K % 32 || mode < 0 || mode > 4) { set_err("gemm_mx_check: bad args"); return -1; }
+    if (mode == 4 && (N % 768 || M % 256)) { set_err("gemm_mx_check: the QKV mode needs N = 3 H, H % 256 == 0"); return -1; }
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHK(hipSetDevice(e->device), -1);
     const size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
-    float *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *C0 = nullptr, *C1 = nullptr, *bias = nullptr;
+    float *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *C0 = nullptr, *C1 = nullptr, *R0 = nullptr, *R1 = nullptr, *bias = nullptr, *lnc = nullptr, *gam = nullptr, *bet = nullptr;
+    float2 *st = nullptr, *lp0 = nullptr, *lp1 = nullptr;
     int rc = -1;
     do {
         if (hipMalloc((void**)&A, nA * 4) || hipMalloc((void**)&W, nW * 4) || hipMalloc((void**)&A2, nA * 4) || hipMalloc((void**)&W2, nW * 4) ||
-            hipMalloc((void**)&C0, nC * 4) || hipMalloc((void**)&C1, nC * 4) || hipMalloc((void**)&bias, (size_t)N * 4)) { set_err("gemm_mx_check: alloc failed"); break; }
-        std::vector<float> ha(nA), hw(nW), hb(N);
-        unsigned s = 777u;
+            hipMalloc((void**)&C0, nC * 4) || hipMalloc((void**)&C1, nC * 4) || hipMalloc((void**)&R0, nC * 4) || hipMalloc((void**)&R1, nC * 4) ||
+            hipMalloc((void**)&bias, (size_t)N * 4) || hipMalloc((void**)&lnc, (size_t)N * 4) || hipMalloc((void**)&gam, (size_t)N * 4) || hipMalloc((void**)&bet, (size_t)N * 4) ||
+            hipMalloc((void**)&st, (size_t)M * 8) || hipMalloc((void**)&lp0, (size_t)M * (N / 64) * 8) || hipMalloc((void**)&lp1, (size_t)M * (N / 64) * 8)) { set_err("gemm_mx_check: alloc failed"); break; }
+        std::vector<float> ha(nA), hw(nW), hb(N), hc(N), hg(N), hbe(N), hr(nC);
+        std::vector<float2> hst(M);
+        unsigned s = 777u + 13u * mode;
         auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 8388608.f - 1.f; };
         for (auto& v : ha) v = rnd() * a_amp;
         for (auto& v : hw) v = rnd() * w_amp;
-        for (auto& v : hb) v = rnd() * 0.1f;
+        for (auto& v : hr) v = rnd() * a_amp;
+        for (int n = 0; n < N; ++n) { hb[n] = rnd() * 0.1f; hc[n] = rnd() * 0.05f; hg[n] = 1.f + 0.3f * rnd(); hbe[n] = 0.2f * rnd(); }
+        for (int m = 0; m < M; ++m) hst[m] = make_float2(0.1f * rnd() * a_amp, (0.5f + 0.4f * rnd()) / a_amp);
         if (hipMemcpy(A, ha.data(), nA * 4, hipMemcpyHostToDevice) || hipMemcpy(W, hw.data(), nW * 4, hipMemcpyHostToDevice) ||
             hipMemcpy(A2, ha.data(), nA * 4, hipMemcpyHostToDevice) || hipMemcpy(W2, hw.data(), nW * 4, hipMemcpyHostToDevice) ||
-            hipMemcpy(bias, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice)) { set_err("gemm_mx_check: copy failed"); break; }
+            hipMemcpy(R0, hr.data(), nC * 4, hipMemcpyHostToDevice) || hipMemcpy(R1, hr.data(), nC * 4, hipMemcpyHostToDevice) ||
+            hipMemcpy(bias, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice) || hipMemcpy(lnc, hc.data(), (size_t)N * 4, hipMemcpyHostToDevice) ||
+            hipMemcpy(gam, hg.data(), (size_t)N * 4, hipMemcpyHostToDevice) || hipMemcpy(bet, hbe.data(), (size_t)N * 4, hipMemcpyHostToDevice) ||
+            hipMemcpy(st, hst.data(), (size_t)M * 8, hipMemcpyHostToDevice) || hipMemset(C0, 0, nC * 4) || hipMemset(C1, 0, nC * 4)) { set_err("gemm_mx_check: copy failed"); break; }
         const int ws = glc_gx_weight_exponent(w_amp);
         const char* m = glc_launch_presplit(e->stream, A, nA);
         if (!m) m = glc_launch_presplit(e->stream, W, nW);
-        if (!m) m = glc_launch_to_gx(e->stream, A2, nA, 0);
-        if (!m) m = glc_launch_to_gx(e->stream, W2, nW, ws);
-        GemmArgs g; g.bias = bias; g.Mpad = M; g.N = N; g.K = K; g.gs_c_plain = 1;
-        g.A = A; g.W = W; g.C = C0;
-        if (!m) m = glc_launch_gemm256s_gs(e->stream, EPI_BIAS, g);
-        g.A = A2; g.W = W2; g.C = C1; g.mx_ws = ws;
-        if (!m) m = glc_launch_gemm256x(e->stream, EPI_BIAS, g);
+        if (!m) m = glc_launch_presplit(e->stream, R0, nC);
+        if (!m) m = glc_launch_to_gx(e->stream, A2, nA, 0, 0);
+        if (!m) m = glc_launch_to_gx(e->stream, W2, nW, ws, 1);
+        if (!m) m = glc_launch_to_gx(e->stream, R1, nC, 0, 0);
+        GemmArgs g; g.bias = bias; g.Mpad = M; g.N = N; g.K = K;
+        int epi = EPI_BIAS;
+        if (mode == 0) g.gs_c_plain = 1;
+        if (mode == 1) { epi = EPI_GELU; g.a_stats = st; g.ln_c = lnc; }
+        if (mode == 2 || mode == 3) { epi = EPI_RESID; if (mode == 2) { g.r_stats = st; g.r_gamma = gam; g.r_beta = bet; } }
+        if (mode == 4) { epi = EPI_QKV; g.a_stats = st; g.ln_c = lnc; g.H = N / 3; g.nh = g.H / 64; g.Sp = 256; g.Mvalid = M; g.qkv_split = 1; }
+        const size_t third = nC / 3;
+        g.A = A; g.W = W; g.C = C0; g.resid = R0; if (mode == 2) g.ln_part = lp0;
+        if (mode == 4) { g.Qh = C0; g.Kh = C0 + third; g.Vt = C0 + 2 * third; }
+        if (!m) m = glc_launch_gemm256s_gs(e->stream, epi, g);
+        g.A = A2; g.W = W2; g.C = C1; g.resid = R1; g.mx_ws = ws; if (mode == 2) g.ln_part = lp1;
+        if (mode == 4) { g.Qh = C1; g.Kh = C1 + third; g.Vt = C1 + 2 * third; }
+        if (!m) m = glc_launch_gemm256x(e->stream, epi, g);
         if (m) { set_err(m); break; }
         std::vector<float> c0(nC), c1(nC);
         if (hipStreamSynchronize(e->stream) || hipMemcpy(c0.data(), C0, nC * 4, hipMemcpyDeviceToHost) || hipMemcpy(c1.data(), C1, nC * 4, hipMemcpyDeviceToHost)) { set_err("gemm_mx_check: readback failed"); break; }
+        // decode the row formats on the host: GS group = [32 hi halves | 32 lo halves]; GX group = [32 hi halves | 32 lo8 | 32 hi8]; QKV units = [8 hi | 8 lo] halves
+        auto half_at = [](const float* base, size_t hidx) { _Float16 hv; memcpy(&hv, reinterpret_cast<const unsigned char*>(base) + 2 * hidx, 2); return (float)hv; };
+        auto fp8_at = [](const float* base, size_t bidx) {
+            const unsigned char b = reinterpret_cast<const unsigned char*>(base)[bidx];
+            const int sg = b >> 7, ex = (b >> 3) & 15, mn = b & 7;
+            const float v = ex == 0 ? ldexpf((float)mn, -9) : ldexpf(1.0f + mn / 8.0f, ex - 7);
+            return sg ? -v : v;
+        };
+        const bool rows_gs = mode == 1 || mode == 2, units = mode == 4;
         double md = 0, mr = 0, sd = 0, sr = 0;
         for (size_t i = 0; i < nC; ++i) {
-            const double d = (double)c1[i] - (double)c0[i], r = c0[i];
-            if (!(fabs(d) <= md)) md = fabs(d);          // (NaN propagates into the maximum)
-            if (fabs(r) > mr) mr = fabs(r);
-            sd += d * d; sr += r * r;
+            double v0, v1;
+            if (rows_gs) {
+                const size_t row = i / N, col = i % N, grp = col >> 5, e5 = col & 31;
+                v0 = half_at(c0.data(), (row * N + grp * 32) * 2 + e5) + half_at(c0.data(), (row * N + grp * 32) * 2 + 32 + e5);
+                v1 = half_at(c1.data(), (row * N + grp * 32) * 2 + e5) + fp8_at(c1.data(), (row * N + grp * 32) * 4 + 64 + 16 * (e5 >> 3) + (e5 & 7)) * ldexp(1.0, -GLC_GX_SHIFT);
+            } else if (units) {
+                const size_t u = i >> 3, j = i & 7;
+                v0 = half_at(c0.data(), u * 16 + j) + half_at(c0.data(), u * 16 + 8 + j);
+                v1 = half_at(c1.data(), u * 16 + j) + half_at(c1.data(), u * 16 + 8 + j);
+            } else { v0 = c0[i]; v1 = c1[i]; }
+            const double d = v1 - v0;
+            if (!(fabs(d) <= md)) md = fabs(d);
+            if (fabs(v0) > mr) mr = fabs(v0);
+            sd += d * d; sr += v0 * v0;
         }
-        out[0] = md; out[1] = mr; out[2] = sqrt(sd / nC); out[3] = sqrt(sr / nC);
+        out[0] = md; out[1] = mr; out[2] = sqrt(sd / nC); out[3] = sqrt(sr / nC); out[4] = 0;
+        if (mode == 2) {
+            std::vector<float2> p0((size_t)M * (N / 64)), p1(p0.size());
+            if (hipMemcpy(p0.data(), lp0, p0.size() * 8, hipMemcpyDeviceToHost) || hipMemcpy(p1.data(), lp1, p1.size() * 8, hipMemcpyDeviceToHost)) { set_err("gemm_mx_check: readback failed"); break; }
+            double pd = 0;
+            for (size_t i = 0; i < p0.size(); ++i) { pd = fmax(pd, fabs((double)p0[i].x - p1[i].x)); pd = fmax(pd, fabs((double)p0[i].y - p1[i].y) / (1.0 + fabs(p0[i].y))); }
+            out[4] = pd;
+        }
         rc = 0;
     } while (0);
-    (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(C0); (void)hipFree(C1); (void)hipFree(bias);
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(C0); (void)hipFree(C1); (void)hipFree(R0); (void)hipFree(R1);
+    (void)hipFree(bias); (void)hipFree(lnc); (void)hipFree(gam); (void)hipFree(bet); (void)hipFree(st); (void)hipFree(lp0); (void)hipFree(lp1);
     return rc;
 }
 

@@ -13,10 +13,11 @@
 //   E: phase A = request group s + 1 (8 pieces per wave), read the f16 fragments (8 + 4); phase B = 16 x 32x32x16 f16      (512 cycles)
 //   O: phase A = read the fp8 fragments (4 + 2 operands of 32 B), wait for my pieces;     phase B =  8 x 32x32x64 scaled   (512 cycles)
 // Hazards: as argued in gemm256s.hip (FL).  Fragment maps: f16 32x32x16 lane (c = l & 31, h = l >> 5) holds row c, k = 16 ks + 8 h + j
-// = chunk 2 ks + h of the group; fp8 32x32x64 lane (c, h) holds bytes [0,16) = MX block 0, slots 16 h .. 16 h + 15, and [16,32) = block 1,
-// same slots (probe: byte y <-> k = 16 h + (y & 15) + 32 (y >> 4)); the scale of block b of row c is taken from lane c + 32 b.  Block 0
-// pairs a_hi8 with w_lo8, block 1 a_lo8 with w_hi8, both over k = 16 h .. 16 h + 15 of the group: A lane = [chunk 6 + h | chunk 4 + h],
-// W lane = [chunk 4 + h | chunk 6 + h].
+// = chunk 2 ks + h of the group; fp8 32x32x64 lane (c, h) holds bytes [0,16) = slots 16 h .. 16 h + 15 of MX block 0 and [16,32) = the
+// same slots of block 1 (probe: byte y <-> k-slot 16 h + (y & 15) + 32 (y >> 4)); the scale of block b of row c is taken from lane
+// c + 32 b.  The lane's 32 bytes are chunks 4 + 2 h and 5 + 2 h of the group — the fp8 parts of elements 16 h .. 16 h + 15, A rows as
+// [lo8 x 8 | hi8 x 8] per 8 elements, W rows as [hi8 x 8 | lo8 x 8] — so slot by slot a_lo8 meets w_hi8 and a_hi8 meets w_lo8 over
+// the same element, and every slot's product carries 2^-(SHIFT + ws): one scale per operand for all blocks (glc_common.h).
 // Accumulators are 32x32 blocks, acc[I][J]: non-transposed launches D[n][m] (lane = m, registers = n: 4 consecutive n per register
 // quad), the V third D[m][n].  Epilogues as gemm256s.hip (LDS-staged 16-byte stores, LayerNorm fold, residual prefetch), reading and
 // writing GX rows where that kernel has GS rows.
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
     const int hsw = (c32 >> 1) & 7;
     const int arow = (wm * 128 + c32) * LINE, wrow = (wn * 64 + c32) * LINE;
     const int ck0 = ((0 + h) ^ hsw) * 16, ck1 = ((2 + h) ^ hsw) * 16;       // f16 k-steps 0 / 1: logical chunks h / 2 + h
-    const int clo = ((4 + h) ^ hsw) * 16, chi = ((6 + h) ^ hsw) * 16;       // fp8 lo8 / hi8 of k = 16 h .. 16 h + 15
-    // e8m0 scales, one per MX block: block 0 from lanes 0-31, block 1 from lanes 32-63.  A (activations, exponent 0): hi8 | lo8;  W: lo8 | hi8.
-    const int sc_a = h ? 127 - GLC_GX_SHIFT : 127;
-    const int sc_w = h ? 127 - p.mx_ws : 127 - p.mx_ws - GLC_GX_SHIFT;
+    const int cx0 = ((4 + 2 * h) ^ hsw) * 16, cx1 = ((5 + 2 * h) ^ hsw) * 16;       // the fp8 parts of elements 16 h .. 16 h + 7 / + 8 .. + 15
+    // e8m0 scales (one per operand, every block): A rows (activations, exponent 0) carry the 2^-SHIFT, W rows their 2^-ws
+    const int sc_a = 127 - GLC_GX_SHIFT;
+    const int sc_w = 127 - p.mx_ws;
 
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, t_loop1 = 0;
     const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xw[j] = ld32(sw + j * 32 * LINE, clo, chi);      // [w_lo8 | w_hi8]
+                for (int j = 0; j < 2; ++j) xw[j] = ld32(sw + j * 32 * LINE, cx0, cx1);      // [w_hi8 w_lo8 | w_hi8 w_lo8] of 2 x 8 elements
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xa[i] = ld32(sa + i * 32 * LINE, chi, clo);      // [a_hi8 | a_lo8]
+                for (int i = 0; i < 4; ++i) xa[i] = ld32(sa + i * 32 * LINE, cx0, cx1);      // [a_lo8 a_hi8 | a_lo8 a_hi8]
             }
         }
         if (odd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 const int n = n0 + wn * 64 + g8 * 8;
                 const unsigned char* rp = reinterpret_cast<const unsigned char*>(p.resid) + (size_t)(m0 + wm * 128 + c * 32 + row) * 4 * N + (n >> 5) * 128;
                 r[k] = *reinterpret_cast<const gs_h8*>(rp + (n & 31) * 2);
-                rl[k] = *reinterpret_cast<const u32x2*>(rp + 64 + (n & 31));
+                rl[k] = *reinterpret_cast<const u32x2*>(rp + 64 + (n & 31) * 2);
             }
         };
         if (EPI == EPI_RESID) load_resid(0, rpre, rpre_lo, rst_pre);
@@ -433,7 +434,7 @@ template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0> const char* launc
 }
 
 // fp32 values -> GX rows in place (weights at load): exponent sc on the fp8 parts
-__global__ __launch_bounds__(256) void to_gx_kernel(float* __restrict__ w, size_t ngroups, float k_hi, float k_lo) {
+__global__ __launch_bounds__(256) void to_gx_kernel(float* __restrict__ w, size_t ngroups, float k_hi, float k_lo, int worder) {
     const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gi >= ngroups) return;
     float* base = w + gi * 32;
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(256) void to_gx_kernel(float* __restrict__ w, size_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float x[8] = {v[2 * i][0], v[2 * i][1], v[2 * i][2], v[2 * i][3], v[2 * i + 1][0], v[2 * i + 1][1], v[2 * i + 1][2], v[2 * i + 1][3]};
-        gx_store8(reinterpret_cast<unsigned char*>(base), 8 * i, x, k_hi, k_lo);
+        if (worder) gx_store8<true>(reinterpret_cast<unsigned char*>(base), 8 * i, x, k_hi, k_lo);
+        else gx_store8<false>(reinterpret_cast<unsigned char*>(base), 8 * i, x, k_hi, k_lo);
     }
 }
 
@@ -476,12 +478,12 @@ const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a) {
     return "gemm256x: bad epilogue";
 }
 
-// In place: n fp32 values (n % 32 == 0) -> GX rows with fp8 exponent sc (glc_common.h): weights at load (sc = glc_gx_weight_exponent),
-// activations in tests (sc = 0).
-const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc) {
+// In place: n fp32 values (n % 32 == 0) -> GX rows with fp8 exponent sc (glc_common.h): weights at load (sc = glc_gx_weight_exponent,
+// worder = 1: [hi8 | lo8] per 8 elements), activations in tests (sc = 0, worder = 0: [lo8 | hi8]).
+const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc, int worder) {
     if (!w || n % 32) return "to_gx: element count must be a multiple of 32";
     if (sc < -40 || sc > 60) return "to_gx: exponent out of range";
     const size_t groups = n / 32;
-    if (groups) hipLaunchKernelGGL(to_gx_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (float*)w, groups, ldexpf(1.0f, sc), ldexpf(1.0f, sc + GLC_GX_SHIFT));
+    if (groups) hipLaunchKernelGGL(to_gx_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (float*)w, groups, ldexpf(1.0f, sc), ldexpf(1.0f, sc + GLC_GX_SHIFT), worder);
     return nullptr;
 }

@@ -156,15 +156,20 @@ __device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]
 }
 
 // "GX" rows (round 3; the operand image of the MX cross-term GEMM, gemm256x.hip): per 32 elements the same 128 bytes as a GS group, as
-//   [32 x f16 hi | 32 x fp8 lo8 | 32 x fp8 hi8],  hi = f16(x),  lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)),  hi8 = e4m3(x * 2^sc)   (saturating)
+//   [32 x f16 hi | 4 x (8 x fp8 lo8, 8 x fp8 hi8)],  hi = f16(x),  lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)),  hi8 = e4m3(x * 2^sc)   (saturating)
+// i.e. the fp8 parts of elements 8 j .. 8 j + 7 sit together in the 16 bytes at 64 + 16 j — activations ("A order") as [lo8 | hi8],
+// weights ("W order") as [hi8 | lo8] — so a producer that holds 8 consecutive values writes two 16-byte pieces, like a GS row.
 // A split product a*w = a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) keeps its f16 MFMA for the first term and runs BOTH cross terms as ONE
-// block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4: MX block 0 = hi8 x lo8, block 1 = lo8 x hi8 over the same 32 k; the
-// 2^-(SHIFT + sc_a + sc_w) comes back through the e8m0 scale operands): the cross terms are ~2^-11 of the product, so their 4-bit
-// operands leave a relative error of ~2^-15 — sixteen times below single f16 operands — at 2 instead of 3 f16-MFMA times per product.
-// x = hi + lo8 * 2^-(SHIFT + sc) also reads the row back to ~15 bits (residual adds, row gathers).  SHIFT = 11: |lo| <= 2^-11 |hi|, so
-// the scaled residual never exceeds |hi| and shares hi8's range; what leaves that range (|x| 2^sc > 448) saturates, i.e. such an
-// element falls back towards single-f16 precision instead of overflowing.
+// block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): lane (row, h) hands over the 32 fp8 bytes of elements 16 h .. 16 h + 15, so
+// the 64 k-slots of the instruction pair a_lo8 with w_hi8 and a_hi8 with w_lo8 slot by slot, and every slot's product carries the same
+// factor 2^-(SHIFT + sc_a + sc_w): ONE e8m0 scale per operand (2^-(SHIFT + sc_a) on A, 2^-sc_w on W) for every block.  The cross terms
+// are ~2^-11 of the product, so their 4-bit operands leave a relative error of ~2^-15 — sixteen times below single f16 operands — at
+// 2 instead of 3 f16-MFMA times per product.  x = hi + lo8 * 2^-(SHIFT + sc) also reads a row back to ~15 bits (residual adds, row
+// gathers).  SHIFT = 11: |lo| <= 2^-11 |hi|, so the scaled residual never exceeds |hi| and shares hi8's range; what leaves that range
+// (|x| 2^sc > 448) saturates, i.e. such an element falls back towards single-f16 precision instead of overflowing.
+#ifndef GLC_GX_SHIFT
 #define GLC_GX_SHIFT 11
+#endif
 __device__ __forceinline__ uint32_t glc_fp8x4(float a, float b, float c, float d) {
     a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
     c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
@@ -173,6 +178,7 @@ __device__ __forceinline__ uint32_t glc_fp8x4(float a, float b, float c, float d
     return (uint32_t)w;
 }
 // eight consecutive elements e0 .. e0 + 7 (e0 % 8 == 0) of a GX row; `row` = the row's first byte; k_hi = 2^sc, k_lo = 2^(sc + SHIFT)
+template <bool WORDER = false>
 __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const float (&v)[8], float k_hi, float k_lo) {
     gs_h8 hi;
     float l[8];
@@ -180,9 +186,9 @@ __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const floa
     for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; l[e] = (v[e] - (float)h) * k_lo; }
     unsigned char* p = row + (e0 >> 5) * 128;
     *reinterpret_cast<gs_h8*>(p + (e0 & 31) * 2) = hi;
-    *reinterpret_cast<u32x2*>(p + 64 + (e0 & 31)) = (u32x2){glc_fp8x4(l[0], l[1], l[2], l[3]), glc_fp8x4(l[4], l[5], l[6], l[7])};
-    *reinterpret_cast<u32x2*>(p + 96 + (e0 & 31)) = (u32x2){glc_fp8x4(v[0] * k_hi, v[1] * k_hi, v[2] * k_hi, v[3] * k_hi),
-                                                           glc_fp8x4(v[4] * k_hi, v[5] * k_hi, v[6] * k_hi, v[7] * k_hi)};
+    const uint32_t l0 = glc_fp8x4(l[0], l[1], l[2], l[3]), l1 = glc_fp8x4(l[4], l[5], l[6], l[7]);
+    const uint32_t h0 = glc_fp8x4(v[0] * k_hi, v[1] * k_hi, v[2] * k_hi, v[3] * k_hi), h1 = glc_fp8x4(v[4] * k_hi, v[5] * k_hi, v[6] * k_hi, v[7] * k_hi);
+    *reinterpret_cast<u32x4*>(p + 64 + (e0 & 31) * 2) = WORDER ? (u32x4){h0, h1, l0, l1} : (u32x4){l0, l1, h0, h1};
 }
 // x = hi + lo8 * inv_lo, inv_lo = 2^-(sc + SHIFT)
 __device__ __forceinline__ void gx_decode8(const gs_h8& hi, const u32x2& lo8, float inv_lo, float (&v)[8]) {
@@ -191,9 +197,10 @@ __device__ __forceinline__ void gx_decode8(const gs_h8& hi, const u32x2& lo8, fl
     v[4] = (float)hi[4] + __builtin_amdgcn_cvt_f32_fp8((int)lo8[1], 0) * inv_lo; v[5] = (float)hi[5] + __builtin_amdgcn_cvt_f32_fp8((int)lo8[1], 1) * inv_lo;
     v[6] = (float)hi[6] + __builtin_amdgcn_cvt_f32_fp8((int)lo8[1], 2) * inv_lo; v[7] = (float)hi[7] + __builtin_amdgcn_cvt_f32_fp8((int)lo8[1], 3) * inv_lo;
 }
+// (activation rows: A order)
 __device__ __forceinline__ void gx_load8(const unsigned char* row, int e0, float (&v)[8], float inv_lo) {
     const unsigned char* p = row + (e0 >> 5) * 128;
-    gx_decode8(*reinterpret_cast<const gs_h8*>(p + (e0 & 31) * 2), *reinterpret_cast<const u32x2*>(p + 64 + (e0 & 31)), inv_lo, v);
+    gx_decode8(*reinterpret_cast<const gs_h8*>(p + (e0 & 31) * 2), *reinterpret_cast<const u32x2*>(p + 64 + (e0 & 31) * 2), inv_lo, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -80,11 +80,12 @@ const char* glc_launch_layernorm(hipStream_t st, int dtype, const void* X, void*
 
 // ---- group-split ("GS") activations of the fp32 mode (rows.hip): a row of K fp32 values kept in the same 4 K bytes as K / 32 groups
 // of [32 hi halves | 32 lo halves] (x = hi + lo), the operand image of the split-f16 GEMMs ----
-const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H);
+// (gx != 0: the rows are written / read in the GX format of the MX cross-term GEMM — same bytes per group, glc_common.h)
+const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H, int gx = 0);
 const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_t* mask, const float* table, const float* gamma,
-                                const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id);
+                                const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id, int gx = 0);
 const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* cls_pos, int c_cap, float* Xs, int* sel_b, int* sel_q,
-                                      unsigned char* tile_flag, int B, int Sp, int H, int C);
+                                      unsigned char* tile_flag, int B, int Sp, int H, int C, int gx = 0);
 // 256x256 LDS-DMA GEMM on GS operands (gemm256s.hip): A [Mpad, K] and W [N, K] in the GS format; three f16 MFMAs per product
 // (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi) on the 16-bit kernel's ring, every 64-byte part fetched once.  EPI_GELU / EPI_BIAS: C in the GS format;
 // EPI_RESID: resid in the GS format, C plain fp32 (the LayerNorm input); EPI_QKV: Q / K / V^T as split-f16 units (qkv_split).
@@ -94,7 +95,10 @@ bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi);
 // EPI_RESID: resid as GX rows, C raw GX rows + ln_part, or plain fp32; EPI_QKV: split-f16 units; LayerNorm fold arguments as gemm256s.
 bool glc_gemm256x_supported(const GemmArgs& a, int epi);
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a);
-const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc);       // in place: n fp32 values -> GX rows, fp8 exponent sc
+const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc, int worder);       // in place: n fp32 values -> GX rows, fp8 exponent sc; worder: weight rows
+#ifndef GLC_GX_SHIFT
+#define GLC_GX_SHIFT 11                     // GX rows: lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)) (glc_common.h)
+#endif
 // fp8 exponent for a weight tensor whose largest magnitude is maxabs: 2^sc maxabs <= 240 (e4m3 saturates at 448)
 inline int glc_gx_weight_exponent(float maxabs) {
     if (!(maxabs > 0.f)) return 0;
@@ -136,7 +140,7 @@ struct AttnArgs {
     unsigned long long* stamps = nullptr;
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
     int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
-    int ctx_gs = 0;                                   // workgroup-shared kernel, split operands: write CTX rows in the GS format (see below)
+    int ctx_gs = 0;                                   // workgroup-shared kernel, split operands: write CTX rows in the GS format (1) or the GX format (2)
     int ksplit = 0;                                   // per-wave band kernel with tile_flag: a workgroup with ONE flagged query tile splits that tile's keys over its 4 waves
     int prec = 0;                                     // workgroup-shared kernel, split units: (engine mask >> 8) & 63 — bits Q, K, V, P, PQ, PK rounded to f16
 };

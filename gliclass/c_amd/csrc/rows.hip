@@ -60,7 +60,16 @@ __device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restri
 // 256-tile LDS-DMA GEMM can fetch hi and lo parts of a 32-deep K step as plain 64-byte row pieces.  Element e of a row lives at
 // halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
 // LayerNorm of one fp32 row by one wave, output in the GS format (8 elements per lane and chunk)
-template <bool MASKED>
+// (GX = true: the same 128-byte groups as GX rows — [32 hi | 32 lo8 | 32 hi8], glc_common.h — for the MX cross-term GEMM; activation exponent 0)
+template <bool GX> __device__ __forceinline__ void row_store8(f16_t* y, int e0, const float (&v)[8]) {
+    if constexpr (GX) gx_store8(reinterpret_cast<unsigned char*>(y), e0, v, 1.0f, (float)(1 << GLC_GX_SHIFT));
+    else gs_store8(y, e0, v);
+}
+template <bool GX> __device__ __forceinline__ void row_load8(const f16_t* y, int e0, float (&v)[8]) {
+    if constexpr (GX) gx_load8(reinterpret_cast<const unsigned char*>(y), e0, v, 1.0f / (float)(1 << GLC_GX_SHIFT));
+    else gs_load8(y, e0, v);
+}
+template <bool MASKED, bool GX = false>
 __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_t* __restrict__ y, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float eps, int H, float mk, int lane) {
     const int nch = H / 8;
@@ -96,15 +105,16 @@ __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_
                 if (MASKED) r *= mk;
                 o[e] = r;
             }
-            gs_store8(y, ch * 8, o);
+            row_store8<GX>(y, ch * 8, o);
         }
     }
 }
+template <bool GX>
 __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int M, int H) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    ln_row_wave_gs<false>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
+    ln_row_wave_gs<false, GX>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
 }
 // decoder backbone, RMSNorm folded into the GEMMs: the embedding rows (plain fp32) enter the pipeline as raw group-split rows + (0, rstd)
 __global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H) {
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict_
     if (rms) stats[row] = make_float2(0.f, (float)(1.0 / sqrt(m2 * invH + mean * mean + (double)eps)));
     else stats[row] = make_float2((float)mean, (float)(1.0 / sqrt(m2 * invH + (double)eps)));
 }
+template <bool GX>
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, f16_t* __restrict__ X,
@@ -158,9 +169,10 @@ __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict
         if (id < 0 || id >= vocab) id = pad_id;
     }
     if (lane == 0) kbias[row] = mk != 0.f ? 0.f : GLC_NEG_BIG;
-    ln_row_wave_gs<true>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane);
+    ln_row_wave_gs<true, GX>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane);
 }
 // pruned last layer: rows the head reads, GS hidden states -> plain fp32 compact rows (that layer runs on the fp32-format kernels)
+template <bool GX>
 __global__ __launch_bounds__(256) void gather_rows_gs_kernel(const f16_t* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
                                                              float* __restrict__ Xs, int* __restrict__ sel_b, int* __restrict__ sel_q,
                                                              unsigned char* __restrict__ tile_flag, int B, int Sp, int H, int C) {
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void gather_rows_gs_kernel(const f16_t* __rest
     const f16_t* src = X + ((size_t)b * Sp + pos) * 2 * H;
     for (int i = lane; i < H / 8; i += 64) {
         float v[8];
-        gs_load8(src, i * 8, v);
+        row_load8<GX>(src, i * 8, v);
         *reinterpret_cast<f32x4*>(Xs + (size_t)r * H + i * 8) = (f32x4){v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(Xs + (size_t)r * H + i * 8 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     }
@@ -410,10 +422,11 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
     return nullptr;
 }
 
-const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H) {
+const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H, int gx) {
     if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm_gs: bad args";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "layernorm_gs: unsupported hidden size";
-    hipLaunchKernelGGL(layernorm_gs_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
+    if (gx) hipLaunchKernelGGL(layernorm_gs_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
+    else hipLaunchKernelGGL(layernorm_gs_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
     return nullptr;
 }
 
@@ -430,19 +443,21 @@ const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, f
 }
 
 const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_t* mask, const float* table, const float* gamma,
-                                const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id) {
+                                const float* beta, float eps, void* X, float* kbias, int B, int S, int Sp, int H, int vocab, int pad_id, int gx) {
     if (B <= 0 || S <= 0 || Sp < S || !ids || !mask || !table || !X || !kbias) return "embed_gs: bad args";
     if (pad_id < 0 || pad_id >= vocab) return "embed_gs: pad id outside vocab";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "embed_gs: unsupported hidden size";
-    hipLaunchKernelGGL(embed_gs_kernel, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id);
+    if (gx) hipLaunchKernelGGL(embed_gs_kernel<true>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id);
+    else hipLaunchKernelGGL(embed_gs_kernel<false>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id);
     return nullptr;
 }
 
 const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* cls_pos, int c_cap, float* Xs, int* sel_b, int* sel_q,
-                                      unsigned char* tile_flag, int B, int Sp, int H, int C) {
+                                      unsigned char* tile_flag, int B, int Sp, int H, int C, int gx) {
     if (B <= 0 || C < 0 || !X || !cls_pos || !Xs || !sel_b || !sel_q || H % 32) return "gather_rows_gs: bad args";
     const int rows = B * (1 + C);
-    hipLaunchKernelGGL(gather_rows_gs_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
+    if (gx) hipLaunchKernelGGL(gather_rows_gs_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
+    else hipLaunchKernelGGL(gather_rows_gs_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
     return nullptr;
 }
 

@@ -116,6 +116,14 @@ class Engine:
         if self.L.glc_debug_set_precision_mask(self.h, int(mask)) != 0:
             raise self._err("glc_debug_set_precision_mask")
 
+    def set_mx(self, on):
+        """MX cross-term pipeline on / off (engine created under GLICLASS_MX=1 or =build)"""
+        if self.L.glc_debug_set_mx(self.h, int(bool(on))) != 0:
+            raise self._err("glc_debug_set_mx")
+
+    def last_mx(self):
+        return bool(self.L.glc_debug_last_forward_mx(self.h))
+
     def range_retries(self):
         """host-buffer forwards repeated with the norms unfused because the folded forward came out non-finite"""
         return int(self.L.glc_debug_range_retries(self.h))

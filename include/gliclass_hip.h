@@ -134,6 +134,13 @@ int glc_debug_set_attention_impl(glc_engine* e, int impl);
  * kernel).  mode 0 off, 1 auto (default: forwards large enough to fill the chip), 2 whenever the shapes allow (tests). */
 int glc_debug_set_group_split(glc_engine* e, int mode);
 int glc_debug_last_forward_group_split(const glc_engine* e);
+/* MX cross-term pipeline: every projection of the full layers as a_hi*w_hi in f16 MFMAs + both cross terms in ONE
+ * block-scaled fp8 MFMA, on "GX" rows.  Needs the GX weight copies, i.e. an engine created under GLICLASS_MX=1 (selected) or =build. */
+int glc_debug_set_mx(glc_engine* e, int on);
+int glc_debug_last_forward_mx(const glc_engine* e);
+/* Developer: stop forwards after a stage and read workspace rows decoded to fp32 (engine.hip). */
+int glc_debug_set_stop(glc_engine* e, int stage);
+int glc_debug_read_workspace(glc_engine* e, int which, int rows, float* out);
 /* Group-split pipeline: LayerNorm folded into the GEMMs around it (1, default: the producer writes raw rows + row statistics, the consumer
  * runs on weights with gamma folded in and finishes (LN(x) W^T + b) in its epilogue) or as kernels of its own (0). */
 int glc_debug_set_ln_fused(glc_engine* e, int on);
@@ -155,7 +162,7 @@ void glc_delta_table(int S, int bucket_size, int max_position, int32_t* out);
 /* Developer microbenchmark of one GEMM shape (16-bit engines): ms per launch, <0 on error. */
 float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which);
 /* Developer check: MX cross-term GEMM against the split-f16 GEMM on the same random operands (engine.hip). */
-int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, double* out);
+int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, int mode, double* out);
 /* Developer microbenchmark of the band attention kernel on the workspace of the last forward (see engine.hip). */
 float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum);
 

@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 2500.0}   # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md); the f32 mode runs f16 MFMAs too (x3 per product)
-MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32": 3}            # split-f16: a_lo*b_hi + a_hi*b_lo + a_hi*b_hi
+MFMA_PER_PRODUCT = {"f16": 1, "bf16": 1, "f32": 3}            # split-f16: a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (MX projections: 1 f16 + 1 fp8 at twice the rate = 2, profile_mode)
 BAR = 1e-3                                                     # /root/reference/ONNX_CONVERTING/test_onnx.py:30
 
 
@@ -260,7 +260,7 @@ def cpu_baseline(cfg, wptrs, S, C_labels, seqs, seqs8):
     return out, logits, ids, mask
 
 
-def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, config_key):
+def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, config_key, mx=False):
     """Per-kernel-class HIP-event profile of 3 forwards on the engine's stream -> the `roofline` object."""
     fl = kernel_flops(cfg, B, S)
     hipl.glc_profile_enable(h, 1)
@@ -298,6 +298,8 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
     except Exception:
         pass
     mpp = MFMA_PER_PRODUCT[dtype]
+    if mx and dom.startswith("gemm"):
+        mpp = 2                    # MX projections: a_hi*w_hi as f16 MFMAs + both cross terms as one fp8 MFMA at twice the f16 rate (attention stays at 3)
     return dict(bound="mfma", kernel=dom, achieved=per[dom]["tflops"], peak=peak, unit="TFLOP/s",
                 frac=round(per[dom]["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_src,
                 flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
@@ -470,8 +472,9 @@ def main():
             logits = (gathered[0] if gathered[0] is not None else runner.logits).cpu().numpy()
             key = f"{args.config}:{args.batch}:{S}"
             roof = None
+            mx_on = bool(hipl.glc_debug_last_forward_mx(h)) if args.dtype == "f32" else False
             if not args.no_profile:
-                roof = profile_mode(hipl, h, runner.step, runner.sync, cfg, B, S, Cn, args.dtype, B / (ev_ms * 1e-3), key)
+                roof = profile_mode(hipl, h, runner.step, runner.sync, cfg, B, S, Cn, args.dtype, B / (ev_ms * 1e-3), key, mx_on)
             # boundary-inclusive step (SURVEY.md §8d protocol): host int64 ids/mask in, H2D, forward, D2H of the logits out
             host_ms = None
             if world == 1:
@@ -490,7 +493,8 @@ def main():
                 n = rids.shape[0]
                 cpu["gpu_vs_cpu_max_prob_err"] = prob_err(logits[:n], ref_logits)
                 cpu["rows_compared"] = n
-            mode_txt = {"f32": "f32 data, split-f16 x3 MFMA products (the product's default mode)", "f16": "f16 MFMA operands (opt-in throughput mode)",
+            mode_txt = {"f32": ("f32 data; projections: a_hi*w_hi in f16 MFMAs + both cross terms in one block-scaled fp8 MFMA (MX, ~2^-15 per product); attention: split-f16 x3 MFMA products (the product's default mode)"
+                                if mx_on else "f32 data, split-f16 x3 MFMA products (the default mode with GLICLASS_MX=0, or a forward too small for the 256-tile pipeline)"), "f16": "f16 MFMA operands (opt-in throughput mode)",
                         "bf16": "bf16 MFMA operands (opt-in throughput mode)"}[args.dtype]
             shape_txt = (f"gliclass-{args.config} (DeBERTa-v3 shape L={cfg.layers} H={cfg.hidden})" if cfg.backbone != 1 else
                          f"gliclass-{args.config} (decoder backbone L={cfg.layers} H={cfg.hidden}, {cfg.heads}q/{cfg.kv_heads}kv x {cfg.head_dim})")
@@ -498,7 +502,7 @@ def main():
                 "metric": f"sequences/sec at batch={args.batch} seq={S}, gliclass-{args.config}; %MFMA-peak",
                 "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-                "dtype": args.dtype, "mode": mode_txt, "data": "synthetic",
+                "dtype": args.dtype, "mode": mode_txt, "mx_projections": mx_on, "data": "synthetic",
                 "config": {"workload": f"{shape_txt}, batch={args.batch} seq={S} labels={Cn}, random-init weights (seed 42), full-length rows",
                            "global_batch": global_rows, "seq_len": S,
                            "parallelism": (f"batch-shard x{world}: one process per GPU, every rank a full batch, no data-path collective" if args.scaling == "weak" else

@@ -796,8 +796,16 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     if (const char* lv = getenv("GLC_LNF")) e->ln_fused = atoi(lv) != 0;      // developer A/B switch
-    // MX cross-term pipeline: GLICLASS_MX=1 builds the GX weight copies and selects it; GLICLASS_MX=build only builds them (glc_debug_set_mx)
-    if (const char* mv = getenv("GLICLASS_MX")) { e->mx_built = dtype == GLC_F32 && !dec && (atoi(mv) != 0 || !strcmp(mv, "build")); e->mx = e->mx_built && atoi(mv) != 0; }
+    // MX cross-term pipeline — the default arithmetic of the large forwards of the default mode since round 3: the
+    // projections of the full layers run a_hi*w_hi in f16 MFMAs and both cross terms in one block-scaled fp8 MFMA (per-label
+    // probabilities within 1e-4 of the split-f16 arithmetic, measured; the bar is 1e-3).  GLICLASS_MX=0: split-f16 projections
+    // everywhere (three f16 MFMAs per product, ~1e-5); GLICLASS_MX=build: GX weight copies built, pipeline off until glc_debug_set_mx.
+    {
+        const char* mv = getenv("GLICLASS_MX");
+        const bool eligible = dtype == GLC_F32 && !dec && e->w_presplit && e->ln_fused && cfg->hidden % 256 == 0 && cfg->inter % 256 == 0 && cfg->layers >= 2;
+        e->mx_built = eligible && !(mv && !strcmp(mv, "0"));
+        e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
+    }
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TOL_PROB = {"f32": 1e-4, "f16": 1e-2, "bf16": 6e-2}
+TOL_MX = 3e-4          # default mode with MX cross-term projections (large forwards): measured 7e-5 worst case at c3; bar 1e-3
 TOL_HID = {"f32": 2e-4, "f16": 6e-2, "bf16": 4e-1}
 GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*_b*_s*.npz")))
 
@@ -623,8 +624,9 @@ def test_group_split_pipeline_vs_oracle_and_plain_fp32(cname, engines, weights_f
             plain = eng.forward(ids, mask)
             assert not eng.last_group_split()
             eng.set_group_split(2)
+            eng.set_mx(False)                 # the split-f16 projections (three f16 MFMAs per product); the MX pipeline has its own test below
             gs = eng.forward(ids, mask)
-            assert eng.last_group_split()
+            assert eng.last_group_split() and not eng.last_mx()
             assert np.isfinite(gs).all()
             assert np.abs(sig(gs) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
             # ... and with LayerNorm as kernels of its own instead of folded into the GEMMs around it (raw rows + row statistics
@@ -637,6 +639,16 @@ def test_group_split_pipeline_vs_oracle_and_plain_fp32(cname, engines, weights_f
             assert np.abs(sig(gs) - sig(unf)).max() <= 1e-4, (B, S)
             assert not np.array_equal(gs, unf), "the LayerNorm switch changed nothing: is the folded path running?"
             assert np.abs(sig(gs) - sig(plain)).max() <= 1e-4, (B, S)     # each sits ~1e-5 from the oracle; GS rows also carry 22 instead of 24 bits
+            # MX cross-term pipeline (the default of large forwards: a_hi*w_hi in f16 MFMAs, both cross terms in one block-scaled fp8
+            # MFMA, GX rows): against the oracle inside a third of the 1e-3 bar, and against the split pipeline
+            eng.set_mx(True)
+            mx = eng.forward(ids, mask)
+            assert eng.last_group_split() and eng.last_mx(), "the MX pipeline did not run"
+            assert np.isfinite(mx).all()
+            assert np.abs(sig(mx) - sig(ref)).max() <= TOL_MX, (B, S)
+            assert np.abs(sig(mx) - sig(gs)).max() <= TOL_MX, (B, S)
+            assert not np.array_equal(mx, gs)
     finally:
         eng.set_group_split(1)
         eng.set_ln_fused(True)
+        eng.set_mx(True)

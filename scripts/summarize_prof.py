@@ -59,8 +59,10 @@ import json
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f16"
 config = sys.argv[3] if len(sys.argv) > 3 else "base:64:1024"
 if dtype == "f32":      # default mode: split-f16 attention (workgroup-shared kernel) and group-split GEMMs (gemm256s GS = last template flag 1)
-    cls = {"attention": r"attn_wg_kernel(IfLb1|<float, true)", "gemm_ffn1_gelu": r"gemm256s_kernelIDF16_Li1ELb0ELb1", "gemm_qkv": r"gemm256s_kernelIDF16_Li3ELb0ELb1",
-           "gemm_ffn2": r"gemm256s_kernelIDF16_Li2ELb0ELb1"}
+    # (round 3: the MX cross-term GEMM gemm256x_kernel<EPI, VMODE, ...> where the MX pipeline runs, else gemm256s GS)
+    cls = {"attention": r"attn_wg_kernel(IfLb1|<float, true)", "gemm_ffn1_gelu": r"gemm256x_kernel(ILi1ELb0|<1, false)|gemm256s_kernelIDF16_Li1ELb0ELb1|gemm256s_kernel<_Float16, 1, false, true",
+           "gemm_qkv": r"gemm256x_kernel(ILi3ELb0|<3, false)|gemm256s_kernelIDF16_Li3ELb0ELb1|gemm256s_kernel<_Float16, 3, false, true",
+           "gemm_ffn2": r"gemm256x_kernel(ILi2ELb0|<2, false)|gemm256s_kernelIDF16_Li2ELb0ELb1|gemm256s_kernel<_Float16, 2, false, true"}
 else:
     cls = {"attention": r"attn_band_kernel", "gemm_ffn1_gelu": r"gemm256s?_kernelIDF16b?_Li1ELb0ELb0", "gemm_qkv": r"gemm256s?_kernelIDF16b?_Li3ELb0ELb0",
            "gemm_ffn2": r"gemm256s?_kernelIDF16b?_Li2ELb0ELb0"}

@@ -1,0 +1,480 @@
+// DeBERTa-v2/v3 disentangled self-attention, workgroup-shared band kernel on "MX tiles" (round 3) — the attention of the MX pipeline.
+//
+// The algebra, the work split (8 waves = 8 consecutive 32-query tiles of one (batch, head); K / V^T tiles once per workgroup through an
+// LDS-DMA ring; the p2c band shared through one LDS image; c2p as the initial accumulator of S^T; saturated tiles per wave), the
+// synchronisation and the vector-memory pipeline are those of attention_wg.hip (split units, NW = 8): read that header first.  What
+// changes is the arithmetic of a product and the operand format that goes with it:
+//   split units      a*b = a_lo*b_hi + a_hi*b_lo + a_hi*b_hi        3 x v_mfma_f32_32x32x16_f16 per 16 columns       (96 cycles)
+//   MX tiles         a*b = a_hi*b_hi                                 1 x v_mfma_f32_32x32x16_f16 per 16 columns       (32 cycles)
+//                        + (a_hi*b_lo + a_lo*b_hi)                   1 x v_mfma_scale_f32_32x32x64_f8f6f4 per 32      (64 cycles)
+// i.e. 2/3 of the matrix-pipe time and half the MFMA instructions (a timing-only build of the split kernel with two f16 MFMAs per
+// product ran 1.10 vs 1.40 ms at c3: scripts/attn_bench.py variant 68).  An operand tile (glc_layout.h "MX tiles") is its four f16
+// units + two MX steps whose lane carries 32 bytes [first | second] = the fp8 parts of 16 columns in the order its tensor always
+// travels in — K, PK, V^T as (lo8 | hi8), Q, PQ, P as (hi8 | lo8) — so every product pairs a (lo8 | hi8) operand with a (hi8 | lo8)
+// one: MX block 0 multiplies lo8 x hi8, block 1 hi8 x lo8, and the 2^-GLC_GX_SHIFT of the lo8 parts comes back through the e8m0 scale
+// of the block that holds them (a lane of half h supplies the scale of block h).  Cross terms are ~2^-11 of a product and come out
+// to ~4 bits: ~2^-15 relative per product (split units: 2^-21; single f16: 2^-11).  The probabilities are split on the fly:
+// P = f16(p) for the f16 MFMAs, p_hi8 = e4m3(p), p_lo8 = e4m3((p - f16(p)) 2^SHIFT) for the scaled one (p <= 2^8 with the deferred
+// rescale: inside the e4m3 range).  Everything else — scores, softmax, the position gathers, the fp32 accumulators — is unchanged.
+#include <stdio.h>
+#include <stdlib.h>
+#include "glc_common.h"
+#include "glc_kernels.h"
+#include "glc_layout.h"
+
+namespace {
+
+constexpr float RESCALE_THR = 8.0f;   // log2 units (as attention.hip)
+constexpr int LROW = 68;              // floats per c2p ring row (2 blocks of 32 + 4 pad)
+constexpr int NW = 8;                 // waves = query tiles per workgroup
+constexpr int LROWP = 32 * (NW + 1) + 4;   // floats per p2c image row
+constexpr int TILEB = GLC_MXT_BYTES;  // one K tile, or one V^T tile
+constexpr int SLOTB = 2 * TILEB;      // ring slot: K tile | V^T tile
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+struct MxFrag { f16x8 f[4]; i32x8 x[2]; };      // a 32-row x 64-column operand tile in registers (32 VGPRs)
+
+__device__ __forceinline__ void glds16_sv(const unsigned char* ubase, unsigned lane_off, void* l) {      // attention_wg.hip
+    const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)l;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(lane_off), "s"(ubase) : "memory");
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wg_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void wg_barrier_all() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ i32x8 cat8(const i32x4& a, const i32x4& b) {
+    i32x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
+
+// ABL: timing-only builds (wrong results; AttnArgs::variant bits 8 / 9 through glc_debug_attn_bench): 1 = without the block-scaled MFMAs,
+// 2 = without the fp8 conversion of the probabilities.
+template <int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int Sp = a.Sp;
+    // e8m0 scales of the block-scaled MFMA (lane half h supplies block h): an operand that travels as (lo8 | hi8) / as (hi8 | lo8)
+    // (both in ONE register: byte 0 = the (lo8 | hi8) value, byte 1 = the (hi8 | lo8) value, picked by the instruction's op_sel)
+    const int SC = h ? (127 | ((127 - GLC_GX_SHIFT) << 8)) : ((127 - GLC_GX_SHIFT) | (127 << 8));
+    // a product on MX tiles: `lh` travels as (lo8 | hi8), `hl` as (hi8 | lo8); D[row of the FIRST argument][row of the second]
+    auto mm_lh_hl = [&](const MxFrag& lh, const MxFrag& hl, f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh.f[s], hl.f[s], acc, 0, 0, 0);
+        if constexpr (ABL != 1) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(lh.x[m], hl.x[m], acc, 0, 0, 0, SC, 1, SC);
+        }
+    };
+    auto mm_hl_lh = [&](const MxFrag& hl, const MxFrag& lh, f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl.f[s], lh.f[s], acc, 0, 0, 0);
+        if constexpr (ABL != 1) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hl.x[m], lh.x[m], acc, 0, 0, 1, SC, 0, SC);
+        }
+    };
+
+    float* c2p_l = reinterpret_cast<float*>(smem_mx) + (size_t)wave * 32 * LROW;                      // this wave's ring [32 q][64 + 4]
+    float* p2c_img = reinterpret_cast<float*>(smem_mx) + (size_t)NW * 32 * LROW;                      // shared [32 keys][LROWP]
+    unsigned char* kv_ring = smem_mx + ((size_t)NW * 32 * LROW + 32 * LROWP) * sizeof(float);         // 3 x (K tile | V^T tile)
+
+    const int nqb = (Sp + 32 * NW - 1) / (32 * NW);
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int bh = xcd + 8 * (jj / nqb);
+    const int Q0 = (jj % nqb) * 32 * NW;
+    const int QX = Q0 + 32 * NW;                        // the query tile whose LOW block is the workgroup's unowned (last high) block
+    if (bh >= a.B * a.nh) return;
+    const int b = bh / a.nh, hh = bh - b * a.nh;
+    const int q0 = Q0 + 32 * wave;
+    const bool active = q0 < Sp;
+    const int q0m = active ? q0 : Sp - 32;
+    const int klen = a.klen[b];
+    if (Q0 >= klen && Q0 > 0) {
+        // every query of this block lies past the row's last attended token: never read by an attended row; store zeros and leave
+        if (active) {
+            unsigned char* row = reinterpret_cast<unsigned char*>(a.CTX) + ((size_t)b * Sp + q0 + c) * 4 * a.H + (size_t)(2 * hh) * 128 + h * 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(row + 16 * i) = (u32x4){0u, 0u, 0u, 0u};
+        }
+        return;
+    }
+
+    const int nt = Sp >> 5;
+    const unsigned char* __restrict__ Qg = reinterpret_cast<const unsigned char*>(a.Qh) + ((size_t)bh * nt + (q0m >> 5)) * TILEB;
+    const unsigned char* __restrict__ Kg = reinterpret_cast<const unsigned char*>(a.Kh) + (size_t)bh * nt * TILEB;
+    const unsigned char* __restrict__ Vg = reinterpret_cast<const unsigned char*>(a.Vt) + (size_t)bh * nt * TILEB;
+    const unsigned char* __restrict__ PKg = reinterpret_cast<const unsigned char*>(a.PK) + (size_t)hh * (a.P >> 5) * TILEB;
+    const unsigned char* __restrict__ PQg = reinterpret_cast<const unsigned char*>(a.PQ) + (size_t)hh * (a.P >> 5) * TILEB;
+    const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
+
+    int nkt = (klen + 31) >> 5;
+    nkt = nkt < 1 ? 1 : (nkt > nt ? nt : nkt);
+    const int kfirst = a.kfirst[b];
+    const int foff = 8 * h;
+
+    // Position rows: otab entry (q - k) + Sp - 1 + 64 = byte offsets of row delta(q - k) in the SPLIT-unit PQ (x) / PK (y) layouts:
+    // (delta >> 5) * 8192 + slot * 32.  In the MX tile of the same rows: f16 unit s at tile + s * 1024 + h * 512 + slot * 16,
+    // MX step m at tile + 4096 + m * 2048 + h * 1024 + slot * 32.
+    const int otab_max = 2 * Sp - 2 + 128;
+    auto block_x = [&](int qb, int t) -> int {
+        int idx = qb - 32 * t - 31 + c + Sp - 1 + 64;
+        idx = idx < 0 ? 0 : (idx > otab_max ? otab_max : idx);
+        return reinterpret_cast<const int*>(a.otab)[2 * idx];
+    };
+    auto pk_of_pq = [&](int x) -> int {                  // same table row in the K layout: its slot is pi32-permuted
+        const int r = (x >> 5) & 31;
+        return x + ((glc_pi32(r) - r) << 5);
+    };
+    auto load_rows = [&](const unsigned char* base, int off, MxFrag& f) __attribute__((always_inline)) {       // gathered table rows: off = split-form offset
+        const unsigned char* pf = base + (off & ~8191) + ((off & 8191) >> 1) + h * 512;
+        const unsigned char* px = base + off + 4096 + h * 1024;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(pf + s * 1024);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) f.x[m] = cat8(*reinterpret_cast<const i32x4*>(px + m * 2048), *reinterpret_cast<const i32x4*>(px + m * 2048 + 16));
+    };
+    // ring images: f16 units as they are (16 B per lane), MX steps re-arranged by the DMA into [64 lanes x first | 64 lanes x second]
+    auto k_tile = [&](int t, MxFrag& f) __attribute__((always_inline)) {
+        const unsigned char* tile = kv_ring + (size_t)(t % 3) * SLOTB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(tile + s * 1024 + lane * 16);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) f.x[m] = cat8(*reinterpret_cast<const i32x4*>(tile + 4096 + m * 2048 + lane * 16), *reinterpret_cast<const i32x4*>(tile + 4096 + m * 2048 + 1024 + lane * 16));
+    };
+    auto band_store = [&](float* dst, const f32x16& v) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = (f32x4){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    };
+    // LDS-DMA of key tile t into ring slot t % 3: wave w moves the 1-KiB pieces 2 w, 2 w + 1 of [K tile | V^T tile].  K tile: pieces 0-3 the
+    // f16 units, 4-7 the two MX steps; V^T tile (pieces 8-15): per 4-KiB sub-tile [2 f16 units | one MX step].  An MX step's two pieces
+    // are its lanes' first / second 16 bytes (per-lane source address: the DMA gathers).
+    const unsigned off16 = lane * 16, off32 = lane * 32;
+    const bool mx_piece = wave < 4 ? wave >= 2 : (wave & 1);          // wave-uniform: this wave's pieces belong to an MX step
+    const int piece_src = (wave & 3) * 2048;                          // byte offset of this wave's piece pair inside its tile (memory and ring image alike)
+    auto uniform_ptr = [](const unsigned char* q) -> const unsigned char* {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto dma_tile = [&](int t) {
+        unsigned char* dst = kv_ring + (size_t)(t % 3) * SLOTB + (wave < 4 ? 0 : TILEB) + piece_src;
+        const unsigned char* src = (wave < 4 ? Kg : Vg) + (size_t)t * TILEB + piece_src;
+        if (mx_piece) {
+            glds16_sv(uniform_ptr(src), off32, dst);
+            glds16_sv(uniform_ptr(src + 16), off32, dst + 1024);
+        } else {
+            glds16_sv(uniform_ptr(src), off16, dst);
+            glds16_sv(uniform_ptr(src + 1024), off16, dst + 1024);
+        }
+    };
+
+    MxFrag qf;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf.f[s] = *reinterpret_cast<const f16x8*>(Qg + s * 1024 + lane * 16);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) qf.x[m] = cat8(*reinterpret_cast<const i32x4*>(Qg + 4096 + m * 2048 + lane * 32), *reinterpret_cast<const i32x4*>(Qg + 4096 + m * 2048 + lane * 32 + 16));
+    dma_tile(0);
+    if (nkt > 1) dma_tile(1);
+    MxFrag kf;
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    const int rr_base = c - 8 * h + 31;
+
+    // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V with V^T from the ring.
+    auto softmax_pv = [&](float (&sv)[16], int kt) __attribute__((always_inline)) {
+        const int k0 = kt * 32;
+        const unsigned char* vtile = kv_ring + (size_t)(kt % 3) * SLOTB + TILEB;
+        // (the two 32-row halves of V^T one after the other: the second half's fragments are read under the first half's MFMAs —
+        //  both resident at once cost 16 registers the loop does not have)
+        f16x8 vf[2];
+        i32x8 vx;
+        auto load_v = [&](int d) __attribute__((always_inline)) {
+            vf[0] = *reinterpret_cast<const f16x8*>(vtile + d * 4096 + lane * 16);
+            vf[1] = *reinterpret_cast<const f16x8*>(vtile + d * 4096 + 1024 + lane * 16);
+            vx = cat8(*reinterpret_cast<const i32x4*>(vtile + d * 4096 + 2048 + lane * 16), *reinterpret_cast<const i32x4*>(vtile + d * 4096 + 3072 + lane * 16));
+        };
+        load_v(0);
+        if (k0 + 32 > kfirst) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sv[i] += b0[i]; sv[4 + i] += b1[i]; sv[8 + i] += b2[i]; sv[12 + i] += b3[i]; }
+        }
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+        mx = fmaxf(mx, sv[15]);
+        if (__builtin_amdgcn_ballot_w64(mx - m > RESCALE_THR) != 0ull) {     // deferred rescale (attention.hip)
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
+        l += psum;
+        // P travels as (hi8 | lo8): f16(p) for the f16 MFMAs (k-step t = keys 16 t + 8 h + j), fp8 parts of the 16 keys for the scaled one
+        f16x8 pf[2];
+        i32x8 px;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[t][j] = (f16_t)sv[8 * t + j];
+        }
+        if constexpr (ABL == 2) { px = qf.x[0]; }
+        else
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q], sv[4 * q + 1], 0, false);
+            wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q + 2], sv[4 * q + 3], wh, true);
+            px[q] = wh;
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (sv[4 * q + e] - (float)pf[q >> 1][4 * (q & 1) + e]) * (float)(1 << GLC_GX_SHIFT);
+            int wl = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
+            wl = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], wl, true);
+            px[4 + q] = wl;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o0, 0, 0, 0);      // O^T[dd][query c]
+        if constexpr (ABL != 1) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o0, 0, 0, 0, SC, 1, SC);
+        __builtin_amdgcn_sched_barrier(0);
+        load_v(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o1, 0, 0, 0);
+        if constexpr (ABL != 1) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o1, 0, 0, 0, SC, 1, SC);
+    };
+
+    // key-tile ranges, workgroup-uniform (attention_wg.hip)
+    int kt_a = Q0 - 31 - a.rsat_pos >= 0 ? (Q0 - 31 - a.rsat_pos) / 32 + 1 : 0;
+    kt_a = kt_a > nkt ? nkt : kt_a;
+    int kt_b = (Q0 + 32 * (NW - 1) + 31 - a.rsat_neg + 31) / 32;
+    kt_b = kt_b < kt_a ? kt_a : (kt_b > nkt ? nkt : kt_b);
+
+    // Saturated key tiles: delta is ONE value d*: c2p = Q_q.PK[d*] a per-query constant, p2c = K_k.PQ[d*] a second product on the same K tile
+    auto sat_tiles = [&](int kt_lo, int kt_hi, int dstar) {
+        if (kt_lo >= kt_hi) return;
+        MxFrag pqb, pkb;                         // broadcast fragments: every row / column is table row d*
+        load_rows(PQg, (dstar >> 5) * 8192 + (dstar & 31) * 32, pqb);
+        load_rows(PKg, (dstar >> 5) * 8192 + glc_pi32(dstar & 31) * 32, pkb);
+        float cq;
+        {
+            f32x16 t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = 0.f;
+            mm_lh_hl(pkb, qf, t);                // every row = PK[d*] . Q_c
+            cq = t[0];
+        }
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            if (kt + 2 < nkt) dma_tile(kt + 2);
+            k_tile(kt, kf);
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = cq;
+            mm_lh_hl(kf, qf, sacc);
+            mm_lh_hl(kf, pqb, sacc);             // + K_k . PQ[d*] (same for every query column)
+            float sv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
+            softmax_pv(sv, kt);
+            wg_barrier_all();
+        }
+    };
+
+    wg_barrier_all();       // tile 0 is in the ring
+    sat_tiles(0, kt_a, a.P - 1);
+
+    if (kt_a < kt_b) {
+        // ---- band prologue: this wave's c2p blocks L(kt_a - 1) and L(kt_a) ----
+        {
+            MxFrag pk;
+            f32x16 bacc;
+            load_rows(PKg, pk_of_pq(block_x(q0, kt_a - 1)), pk);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+            mm_lh_hl(pk, qf, bacc);
+            band_store(c2p_l + c * LROW + 32, bacc);            // ring half 1
+            load_rows(PKg, pk_of_pq(block_x(q0, kt_a)), pk);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+            mm_lh_hl(pk, qf, bacc);
+            band_store(c2p_l + c * LROW, bacc);                 // ring half 0
+            wave_lds_sync();
+        }
+        const float* c2p_even = c2p_l + c * LROW + rr_base;
+        MxFrag pq, pqx;
+        load_rows(PQg, block_x(q0, kt_a), pq);
+        if ((kt_a % NW) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
+        int od_n = block_x(q0, kt_a + 1);
+        int odx_n = block_x(QX, kt_a + 1);
+        auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
+            const bool extra = (kt % NW) == wave;               // wave-uniform: this wave also computes the block nobody owns
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // everything requested during tile kt - 1 (rows, offsets, my DMA pieces of tile kt + 1)
+            MxFrag pk;
+            const int od = od_n, odx = odx_n;
+            od_n = block_x(q0, kt + 2);
+            odx_n = block_x(QX, kt + 2);
+            k_tile(kt, kf);
+            float* img = p2c_img;
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kc = 16 * (i >> 3) + (i & 7);
+                sacc[i] = xr ? c2p_l[c * LROW + ((rr_base - kc) ^ 32)] : c2p_even[-kc];
+            }
+            // ---- p2c: low block of this wave, and, one wave per tile, the high block of the last wave ----
+            f32x16 bacc, bacc2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+            mm_hl_lh(pq, kf, bacc);
+            if (extra) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bacc2[i] = 0.f;
+                mm_hl_lh(pqx, kf, bacc2);
+            }
+            // ---- S^T = K Q^T + c2p ----
+            mm_lh_hl(kf, qf, sacc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (((kt + 1) % NW) == wave) load_rows(PQg, odx, pqx);
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(PKg, pk_of_pq(od), pk);
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(PQg, od, pq);
+            __builtin_amdgcn_sched_barrier(0);
+            wg_barrier_lds();                                   // X: every wave has finished gathering the previous tile's image
+            band_store(img + c * LROWP + 32 * wave, bacc);
+            if (extra) band_store(img + c * LROWP + 32 * NW, bacc2);
+            wg_barrier_lds();                                   // Y: image complete; tile kt + 1 is in the ring for everyone
+            dma_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float sv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kc = 16 * (i >> 3) + (i & 7);
+                const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);
+                sv[i] = sacc[i] + img[(prow + 4 * h) * LROWP + 32 * wave + rr_base - kc];
+            }
+            f32x16 cacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
+            mm_lh_hl(pk, qf, cacc);                             // c2p of L(kt + 1)  [rr][query c]
+            softmax_pv(sv, kt);
+            band_store(c2p_l + c * LROW + (xr ^ 32), cacc);
+        };
+        for (int kt = kt_a;;) {
+            band_tile(kt, 0);
+            if (++kt >= kt_b) break;
+            band_tile(kt, 32);
+            if (++kt >= kt_b) break;
+        }
+    }
+
+    sat_tiles(kt_b, nkt, 0);
+
+    if (!active) return;
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // GX context rows (as attention_wg.hip, ctx_gs == 2)
+    unsigned char* row = reinterpret_cast<unsigned char*>(a.CTX) + ((size_t)b * Sp + q0 + c) * 4 * a.H;
+    auto store_gx = [&](const f32x16& o, int col0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float own_a = o[8 * p + e] * inv, own_b = o[8 * p + 4 + e] * inv;
+                const float got = __shfl_xor(h ? own_a : own_b, 32, 64);
+                v[e] = h ? got : own_a;
+                v[4 + e] = h ? own_b : got;
+            }
+            gx_store8(row, col0 + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT));
+        }
+    };
+    store_gx(o0, 64 * hh);
+    store_gx(o1, 64 * hh + 32);
+}
+
+constexpr size_t mx_lds_bytes() { return ((size_t)NW * 32 * LROW + 32 * LROWP) * sizeof(float) + 3 * SLOTB; }
+
+// split-f16 units [8 hi | 8 lo] of a Q / K layout tensor (rows in tiles of 32, 64 columns: the position tables at load) -> MX tiles;
+// hl != 0: the tensor travels as (hi8 | lo8) (PQ), else as (lo8 | hi8) (PK).  One thread per (tile, lane slot r): the row's 64 columns.
+__global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int ntiles, int hl) {
+    const int tile = blockIdx.x, r = threadIdx.x & 31, half = threadIdx.x >> 5;      // half: columns 32 half .. 32 half + 31
+    if (tile >= ntiles) return;
+    const unsigned char* st = src + (size_t)tile * 8192;
+    unsigned char* dt = dst + (size_t)tile * 8192;
+    for (int g = 4 * half; g < 4 * half + 4; ++g) {           // 8 columns at a time: e0 = 8 g -> unit s = g >> 1, lane half h = g & 1
+        const int s = g >> 1, hh = g & 1;
+        const f16_t* u = reinterpret_cast<const f16_t*>(st + s * 2048 + (32 * hh + r) * 32);
+        float v[8];
+        gs_h8 hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = u[j]; v[j] = (float)u[j] + (float)u[8 + j]; }
+        *reinterpret_cast<gs_h8*>(dt + glc_mxt_f16(0, r, 8 * g)) = hi;
+        float lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = (v[j] - (float)hi[j]) * (float)(1 << GLC_GX_SHIFT);
+        const u32x2 l8 = {glc_fp8x4(lo[0], lo[1], lo[2], lo[3]), glc_fp8x4(lo[4], lo[5], lo[6], lo[7])};
+        const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
+        unsigned char* px = dt + glc_mxt_mx(0, r, 8 * g);
+        *reinterpret_cast<u32x2*>(px) = hl ? h8 : l8;
+        *reinterpret_cast<u32x2*>(px + 16) = hl ? l8 : h8;
+    }
+}
+
+}  // namespace
+
+// Same contract as glc_launch_attention_wg with split units, except: Qh / Kh / Vt / PQ / PK hold MX tiles (glc_layout.h) and CTX is
+// written as GX rows; otab is the split-unit offset table (engine.hip).  No row selection, no tile flags (the pruned layer keeps its kernel).
+const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a) {
+    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(mx): null pointer";
+    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx): bad shape";
+    if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
+    static std::atomic<unsigned> raised{0};
+    constexpr size_t lds = mx_lds_bytes();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
+    if (a.variant & 256) {
+        static std::atomic<unsigned> r1{0};
+        if (!glc_raise_lds_limit(attn_mx_kernel<1>, (int)lds, r1)) return "attention(mx): cannot raise the dynamic LDS limit";
+        hipLaunchKernelGGL(attn_mx_kernel<1>, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    } else if (a.variant & 512) {
+        static std::atomic<unsigned> r2{0};
+        if (!glc_raise_lds_limit(attn_mx_kernel<2>, (int)lds, r2)) return "attention(mx): cannot raise the dynamic LDS limit";
+        hipLaunchKernelGGL(attn_mx_kernel<2>, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    } else {
+        if (!glc_raise_lds_limit(attn_mx_kernel<0>, (int)lds, raised)) return "attention(mx): cannot raise the dynamic LDS limit";
+        hipLaunchKernelGGL(attn_mx_kernel<0>, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    }
+    return nullptr;
+}
+
+// nrows rows (a multiple of 32) x 64 columns x nheads tensors in split units -> MX tiles (position tables at load)
+const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl) {
+    if (!src || !dst || ntiles <= 0) return "units_to_mxt: bad args";
+    hipLaunchKernelGGL(units_to_mxt_kernel, dim3(ntiles), dim3(64), 0, st, (const unsigned char*)src, (unsigned char*)dst, ntiles, hl);
+    return nullptr;
+}

@@ -76,7 +76,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them).
 // PD (split units): precision-budget build — AttnArgs::prec rounds operand tensors to f16 at run time by zeroing their lo halves
 // (bits: 1 Q, 2 K, 4 V^T, 8 P, 16 PQ rows, 32 PK rows); numerically the kernel that never fetches / forms them, at unchanged cost.
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false, bool PD = false>
+// NMM (split units): MFMAs per split product — 3; 2 = TIMING-ONLY build without the a_lo * b_hi MFMA (wrong results: what a cheaper
+// cross-term form could gain at most, scripts/attn_bench.py variant bit 6).
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false, bool PD = false, int NMM = 3>
 __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     static_assert(!PD || SPLIT, "precision switches act on split units");
     static_assert(!STAG || (NW == 8 && !KVG), "the stagger pairs the two 4-wave halves of an 8-wave workgroup");
@@ -84,6 +86,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
     static_assert(!SPLIT || sizeof(T) == 4, "split operands live in the fp32 layouts");
     static_assert(SPLIT || sizeof(T) == 2, "16-bit operands or split-f16 units");
     typedef typename WgFrag<SPLIT, T>::type frag_t;
+    auto mm = [](const frag_t& x, const frag_t& y, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (SPLIT && NMM == 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.hi, y.lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.hi, y.hi, acc, 0, 0, 0);
+        } else mma32(x, y, acc);
+    };
     constexpr int UNITB = 512 * (int)sizeof(T);      // bytes of one fragment unit (64 lanes x 8 elements)
     constexpr int TILEB = 4 * UNITB;                 // one K tile, or one V^T tile
     constexpr int NPIECE = (VGL ? 1 : 2) * TILEB / 1024;     // 1-KiB DMA pieces per key tile (K then V^T, or K only): 2 per wave
@@ -296,8 +304,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pfr[j] = (T)sv[8 * t + j];
             }
-            mma32(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
-            mma32(vt[1][t], pfr, o1);     //                   dd + 32
+            mm(vt[0][t], pfr, o0);     // O^T[dd][query c], dd = (i&3) + 8*(i>>2) + 4h
+            mm(vt[1][t], pfr, o1);     //                   dd + 32
         }
     };
 
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) t[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pkb[s], qf[s], t);            // every row = PK[d*] . Q_c
+            for (int s = 0; s < 4; ++s) mm(pkb[s], qf[s], t);            // every row = PK[d*] . Q_c
             cq = t[0];
         }
         for (int kt = kt_lo; kt < kt_hi; ++kt) {
@@ -335,9 +343,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[i] = cq;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+            for (int s = 0; s < 4; ++s) mm(kf[s], qf[s], sacc);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(kf[s], pqb[s], sacc);        // + K_k . PQ[d*] (same for every query column)
+            for (int s = 0; s < 4; ++s) mm(kf[s], pqb[s], sacc);        // + K_k . PQ[d*] (same for every query column)
             if constexpr (KVG) k_tile(kt + 1 < nkt ? kt + 1 : kt, kf);
             float sv[16];
 #pragma unroll
@@ -359,13 +367,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+            for (int s = 0; s < 4; ++s) mm(pk[s], qf[s], bacc);
             band_store(c2p_l + c * LROW + 32, bacc);            // ring half 1
             load_rows(PKg, block_delta(q0, kt_a).y, pk);
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], bacc);
+            for (int s = 0; s < 4; ++s) mm(pk[s], qf[s], bacc);
             band_store(c2p_l + c * LROW, bacc);                 // ring half 0
             wave_lds_sync();
         }
@@ -430,16 +438,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pq[s], kf[s], bacc);
+            for (int s = 0; s < 4; ++s) mm(pq[s], kf[s], bacc);
             if (extra) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) bacc2[i] = 0.f;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) mma32(pqx[s], kf[s], bacc2);
+                for (int s = 0; s < 4; ++s) mm(pqx[s], kf[s], bacc2);
             }
             // ---- S^T = K Q^T + c2p ----
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(kf[s], qf[s], sacc);
+            for (int s = 0; s < 4; ++s) mm(kf[s], qf[s], sacc);
             // requests for the next tile, into the registers whose last MFMA has just issued
             // (request order pinned — conditional rows, PK rows, PQ rows, later the DMA: the PK rows are consumed first, and the wait the
             // compiler places there counts the younger requests; a conditional request between them made that wait a vmcnt(0))
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mma32(pk[s], qf[s], cacc);             // c2p of L(kt + 1)  [rr][query c]
+            for (int s = 0; s < 4; ++s) mm(pk[s], qf[s], cacc);             // c2p of L(kt + 1)  [rr][query c]
             stamp(4);                                           // seg 4: DMA request, image gather (waits for S^T), c2p MFMA issue
             softmax_pv(sv, kt);
             band_store(c2p_l + c * LROW + (xr ^ 32), cacc);     // over the old high block (its gather is long retired)
@@ -564,19 +572,19 @@ template <typename T, bool SPLIT, int NW, bool KVG, bool STAG, bool VGL> constex
                 : ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + 3 * 2 * 4 * 512 * sizeof(T);
 }
 
-template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false, bool PD = false> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
+template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL = false, bool DIAG = false, bool PD = false, int NMM = 3> const char* launch_wg(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> raised{0};
     constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG, VGL>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
+    if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD, NMM>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
     static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD>, 64 * NW, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD, NMM>, 64 * NW, lds);
         fprintf(stderr, "[attn_wg] NW=%d lds=%zu bytes, occupancy API: %d workgroup(s) per CU\n", NW, lds, nb);
     }
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
-    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD, NMM>), dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
     return nullptr;
 }
 
@@ -592,6 +600,7 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
         if (!a.split) return "attention(wg): the fp32 mode runs this kernel on split-f16 units only";
         if (a.stamps) return launch_wg<float, true, 8, false, false, false, true>(st, a);
         if (a.prec) return launch_wg<float, true, 8, false, false, false, false, true>(st, a);      // precision-budget build
+        if (a.variant & 64) return launch_wg<float, true, 8, false, false, false, false, false, 2>(st, a);      // timing-only: two MFMAs per product
         // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
         static const bool stag_default = getenv("GLC_ATTN_STAG") != nullptr && atoi(getenv("GLC_ATTN_STAG")) != 0;
         if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);

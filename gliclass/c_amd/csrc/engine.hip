@@ -62,6 +62,7 @@ struct LayerW {
     void *W1f = nullptr, *Wqkvf = nullptr;
     float *c1 = nullptr, *d1 = nullptr, *cq = nullptr, *dq = nullptr;
     // MX pipeline (glc_engine::mx): the projection weights once more as GX rows (glc_common.h) with their fp8 exponents
+    void *PKm = nullptr, *PQm = nullptr;                                     // the position tables as MX tiles (attention_mx.hip)
     void *Wqkv_x = nullptr, *Wqkvf_x = nullptr, *Wo_x = nullptr, *W1f_x = nullptr, *W2_x = nullptr;
     int ws_qkv = 0, ws_qkvf = 0, ws_o = 0, ws_1f = 0, ws_2 = 0;
 };
@@ -77,6 +78,7 @@ struct glc_engine {
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     bool mx_built = false, mx = false;   // MX cross-term projections (gemm256x.hip) on GX rows: weights present / pipeline selected (GLICLASS_MX, glc_debug_set_mx)
     bool last_mx = false;                // the last forward ran the MX pipeline
+    bool mx_attn = true;                 // MX pipeline: attention on MX tiles (attention_mx.hip); false: split-f16 units (GLC_MX_ATTN=0, glc_debug_set_mx_attention)
     int debug_stop = -1;                 // developer: leave run_forward after stage (10 * layer + k), k = 0 QKV, 1 attention, 2 attn-out, 3 FFN1, 4 FFN2 (+ LayerNorm): workspace inspection
     int prec_mask = 0;              // precision-budget switches (PM_* of glc_kernels.h; glc_debug_set_precision_mask): operands rounded to f16 in the group-split pipeline
     int gs_mode = 1;                // fp32 mode, group-split activations + 256-tile LDS-DMA GEMMs: 0 off, 1 auto (large shapes), 2 whenever the shapes allow (tests)
@@ -505,7 +507,8 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         g.Mpad = Mpad; g.N = 3 * H; g.K = H; g.Mvalid = M; g.Sp = Sp; g.nh = nh; g.H = H; g.qkv_split = asplit;
         if (last) break;
         if (x_raw) { g.W = w.Wqkvf; g.bias = w.dq; g.a_stats = e->statsA; g.ln_c = w.cq; }
-        if (mx) { g.W = x_raw ? w.Wqkvf_x : w.Wqkv_x; g.mx_ws = x_raw ? w.ws_qkvf : w.ws_qkv; }
+        const bool mxa = mx && e->mx_attn && w.PKm && w.PQm;       // attention of this layer on MX tiles
+        if (mx) { g.W = x_raw ? w.Wqkvf_x : w.Wqkv_x; g.mx_ws = x_raw ? w.ws_qkvf : w.ws_qkv; g.qkv_mxt = mxa ? 1 : 0; }
         const int pm = gs ? e->prec_mask : 0;
         g.prec = pm & 3;
         { Prof p(e, PC_QKV); KCHK(gs ? gemm_gs(EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
@@ -515,7 +518,8 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
-        { Prof p(e, PC_ATTN); KCHK(launch_band(a), false); }
+        if (mxa) { a.PK = w.PKm; a.PQ = w.PQm; }
+        { Prof p(e, PC_ATTN); KCHK(mxa ? glc_launch_attention_mx(st, a) : launch_band(a), false); }
         if (e->debug_stop == 10 * l + 1) return true;
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
@@ -802,9 +806,10 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     // everywhere (three f16 MFMAs per product, ~1e-5); GLICLASS_MX=build: GX weight copies built, pipeline off until glc_debug_set_mx.
     {
         const char* mv = getenv("GLICLASS_MX");
-        const bool eligible = dtype == GLC_F32 && !dec && e->w_presplit && e->ln_fused && cfg->hidden % 256 == 0 && cfg->inter % 256 == 0 && cfg->layers >= 2;
+        const bool eligible = dtype == GLC_F32 && !dec && e->w_presplit && e->attn_split && e->ln_fused && cfg->hidden % 256 == 0 && cfg->inter % 256 == 0 && cfg->layers >= 2;
         e->mx_built = eligible && !(mv && !strcmp(mv, "0"));
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
+        if (const char* av = getenv("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
     }
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
@@ -961,6 +966,13 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                     const float* src3[3] = {wq.data(), t[2], t[4]};
                     for (int q = 0; q < 3; ++q) for (size_t n = 0; n < (size_t)H; ++n) for (int k = 0; k < H; ++k) xh[(q * (size_t)H + n) * H + k] = src3[q][n * H + k] * tp[14][k];
                     lok = to_gx(xh.data(), 3 * HH, w.Wqkvf_x, w.ws_qkvf);
+                }
+                if (lok && w.PKs && w.PQs) {      // the position tables as MX tiles: PQ travels as (hi8 | lo8), PK as (lo8 | hi8)
+                    w.PKm = dmalloc(e, (size_t)nh * P * 64 * es);
+                    w.PQm = dmalloc(e, (size_t)nh * P * 64 * es);
+                    const char* pm = (w.PKm && w.PQm) ? glc_launch_units_to_mxt(e->stream, w.PKs, w.PKm, nh * (P / 32), 0) : "MX position tables: allocation failed";
+                    if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PQs, w.PQm, nh * (P / 32), 1);
+                    if (pm) { set_err(pm); lok = false; }
                 }
                 if (!lok) break;
             }
@@ -1247,6 +1259,8 @@ int glc_debug_set_mx(glc_engine* e, int on) {
     return 0;
 }
 int glc_debug_last_forward_mx(const glc_engine* e) { return e ? (e->last_mx ? 1 : 0) : -1; }
+/* MX pipeline: attention on MX tiles (1, default) or on split-f16 units (0). */
+int glc_debug_set_mx_attention(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx_attn = on != 0; return 0; }
 /* Developer: stop the next forwards after stage 10 * layer + k (k = 0 QKV, 1 attention, 2 attention-output, 3 FFN1, 4 FFN2 + LayerNorm;
  * -1 = run to the end; logits are garbage when stopped) and read workspace rows as fp32: which = 0 X, 1 H1, 2 CTX, 3 FF (row formats
  * decoded: GX after an MX forward, GS after a group-split one), 4 T1 (plain fp32), 5 statsA, 6 statsB (2 floats per row). */
@@ -1516,10 +1530,15 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const LayerW& w = e->layers[0];
     const bool sp = e->dtype == GLC_F32;
     AttnArgs a{e->Qh, e->Kh, e->Vt, sp ? w.PKs : w.PK, sp ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 59; a.otab = e->otabs[Sp]; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring; bits 4 / 5: wg kernel with / without the half-tile stagger
+    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 123; a.otab = e->otabs[Sp]; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring; bits 4 / 5: wg kernel with / without the half-tile stagger
     hipStream_t st = e->stream;
     const bool wg = (variant & 4) != 0;                       // bit 2: the workgroup-shared kernel (attention_wg.hip)
-    auto launch = [&]() -> const char* { return wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
+    const bool mxk = (variant & 128) != 0;                    // bit 7: the MX-tile kernel (attention_mx.hip) on the MX tiles the last (MX) forward left; bits 8 / 9: its timing-only builds
+    if (mxk) {
+        if (!(sp && e->last_mx && e->mx_attn && w.PKm && w.PQm)) { set_err("attn_bench: the MX kernel needs a previous forward of the MX pipeline with MX attention"); return -1.f; }
+        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512);
+    }
+    auto launch = [&]() -> const char* { return mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
     for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);
     for (int i = 0; i < iters; ++i) launch();
@@ -1532,7 +1551,8 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         float* tmp = nullptr;
         HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)), -1.f);
         std::vector<float> h(n);
-        const char* m = glc_launch_to_f32(st, e->dtype, e->CTX, tmp, n);
+        const char* m = mxk ? nullptr : glc_launch_to_f32(st, e->dtype, e->CTX, tmp, n);
+        if (mxk) { HIPCHK(hipMemsetAsync(tmp, 0, n * sizeof(float), st), -1.f); }        // (GX rows: no checksum)
         hipError_t r = m ? hipErrorUnknown : hipMemcpyAsync(h.data(), tmp, n * sizeof(float), hipMemcpyDeviceToHost, st);
         if (r == hipSuccess) r = hipStreamSynchronize(st);
         (void)hipFree(tmp);
@@ -1541,7 +1561,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         for (size_t i = 0; i < n; ++i) { s1 += h[i]; s2 += (double)h[i] * h[i]; }
         checksum[0] = s1; checksum[1] = s2;
     }
-    if (stamps && wg && sp && !(variant & 57)) {       // the split-f16 workgroup kernel, stamped build: 64 workgroups x 8 waves x 8 counters
+    if (stamps && wg && sp && !(variant & 121)) {       // the split-f16 workgroup kernel, stamped build: 64 workgroups x 8 waves x 8 counters
         unsigned long long* dbuf = nullptr;
         const size_t ns = 64 * 8 * 8;
         if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {

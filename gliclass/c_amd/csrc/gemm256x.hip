@@ -337,6 +337,20 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                         while (sq >= p.Sp) { sq -= p.Sp; ++b; }
                         const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;
                         const int bh = b * p.nh + hh;
+                        if (p.qkv_mxt) {        // MX tiles (glc_layout.h): f16 unit piece + the fp8 parts, Q as (hi8 | lo8), K as (lo8 | hi8)
+                            float lo8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) lo8[e] = (v[e] - (float)o[e]) * kLo;
+                            const u32x2 l8 = {glc_fp8x4(lo8[0], lo8[1], lo8[2], lo8[3]), glc_fp8x4(lo8[4], lo8[5], lo8[6], lo8[7])};
+                            const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
+                            const int tile = bh * (p.Sp >> 5) + (sq >> 5), slot = which == 0 ? (sq & 31) : glc_pi32(sq & 31);
+                            unsigned char* bq = reinterpret_cast<unsigned char*>(which == 0 ? p.Qh : p.Kh);
+                            *reinterpret_cast<vec8T*>(bq + glc_mxt_f16(tile, slot, dd)) = o;
+                            unsigned char* px = bq + glc_mxt_mx(tile, slot, dd);
+                            *reinterpret_cast<u32x2*>(px) = which == 0 ? h8 : l8;
+                            *reinterpret_cast<u32x2*>(px + 16) = which == 0 ? l8 : h8;
+                            continue;
+                        }
                         const size_t off = which == 0 ? glc_qoff(p.Sp, bh, sq, dd) : glc_koff(p.Sp, bh, sq, dd);
                         T* base = reinterpret_cast<T*>(which == 0 ? p.Qh : p.Kh);
                         *reinterpret_cast<vec8T*>(base + 2 * off) = o;          // split-f16 unit [8 hi | 8 lo]
@@ -395,6 +409,21 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 if (m < p.Mvalid) {
                     int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
                     while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                    if (p.qkv_mxt) {            // V^T MX tiles: (lo8 | hi8)
+                        const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        float r8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) r8[e] = (x8[e] - (float)o[e]) * kLo;
+                        const u32x2 l8 = {glc_fp8x4(r8[0], r8[1], r8[2], r8[3]), glc_fp8x4(r8[4], r8[5], r8[6], r8[7])};
+                        const u32x2 h8 = {glc_fp8x4(x8[0], x8[1], x8[2], x8[3]), glc_fp8x4(x8[4], x8[5], x8[6], x8[7])};
+                        const int tile = (b * p.nh + hh) * (p.Sp >> 5) + (sq >> 5);
+                        unsigned char* bv = reinterpret_cast<unsigned char*>(p.Vt);
+                        *reinterpret_cast<vec8T*>(bv + glc_mxt_v_f16(tile, dd, sq)) = o;
+                        unsigned char* px = bv + glc_mxt_v_mx(tile, dd, sq);
+                        *reinterpret_cast<u32x2*>(px) = l8;
+                        *reinterpret_cast<u32x2*>(px + 16) = h8;
+                        continue;
+                    }
                     const size_t off = glc_voff(p.Sp, b * p.nh + hh, dd, sq);
                     *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + 2 * off) = o;
                     *reinterpret_cast<vec8T*>(reinterpret_cast<T*>(p.Vt) + 2 * off + 8) = ol;

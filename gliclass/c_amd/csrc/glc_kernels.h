@@ -48,6 +48,7 @@ struct GemmArgs {
     // bit 2 = the GS residual rows
     int prec = 0;
     int prio_mode = -1;                     // gemm256x: wave priority policy of the main loop (-1: default / GLC_GEMM_PRIO; developer A/B)
+    int qkv_mxt = 0;                        // gemm256x, EPI_QKV: write Q / K / V^T as MX tiles (glc_layout.h) for attention_mx.hip instead of split-f16 units
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
 };
 // Precision-budget mask of an engine (developer, gliclass_hip.h glc_debug_set_precision_mask): a set bit rounds that operand of the
@@ -149,6 +150,12 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
 // impl 3: workgroup-shared band kernel (attention_wg.hip): K / V^T tiles through an LDS-DMA ring, p2c band shared by the waves of a
 // workgroup.  16-bit operands, or the fp32 mode's split-f16 units (a.split).
 const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a);
+
+// Workgroup-shared band kernel on MX tiles (attention_mx.hip; the attention of the MX pipeline): Qh / Kh / Vt / PQ / PK are MX tiles
+// (glc_layout.h), CTX is written as GX rows; otab is the split-unit offset table.
+const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a);
+// position tables at load: split-f16 units (Q / K layout, ntiles tiles of 32 rows x 64 columns) -> MX tiles; hl: (hi8 | lo8) order (PQ), else (lo8 | hi8) (PK)
+const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl);
 
 #include <atomic>
 // CU count of the CURRENT device, cached per device ordinal (a session may span GPUs of different sizes)

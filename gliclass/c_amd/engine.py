@@ -121,6 +121,10 @@ class Engine:
         if self.L.glc_debug_set_mx(self.h, int(bool(on))) != 0:
             raise self._err("glc_debug_set_mx")
 
+    def set_mx_attention(self, on):
+        """MX pipeline: attention on MX tiles (default) or on split-f16 units"""
+        self.L.glc_debug_set_mx_attention(self.h, int(bool(on)))
+
     def last_mx(self):
         return bool(self.L.glc_debug_last_forward_mx(self.h))
 

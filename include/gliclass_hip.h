@@ -138,6 +138,7 @@ int glc_debug_last_forward_group_split(const glc_engine* e);
  * block-scaled fp8 MFMA, on "GX" rows.  Needs the GX weight copies, i.e. an engine created under GLICLASS_MX=1 (selected) or =build. */
 int glc_debug_set_mx(glc_engine* e, int on);
 int glc_debug_last_forward_mx(const glc_engine* e);
+int glc_debug_set_mx_attention(glc_engine* e, int on);     /* MX pipeline: attention on MX tiles (default) / on split-f16 units */
 /* Developer: stop forwards after a stage and read workspace rows decoded to fp32 (engine.hip). */
 int glc_debug_set_stop(glc_engine* e, int stage);
 int glc_debug_read_workspace(glc_engine* e, int which, int rows, float* out);

@@ -14,6 +14,8 @@ w = weights.make_weights(cfg, 42)
 ids, mask, _ = synth.make_inputs(cfg, B, S, 3, seed=5)
 e = Engine(cfg, w, dtype="f32")
 e.set_length_buckets(1); e.set_group_split(2)
+# GLC_BISECT_ATTN=1: compare MX attention (on) against the MX pipeline with split-unit attention; else MX pipeline vs group-split pipeline
+ATT = bool(os.environ.get("GLC_BISECT_ATTN"))
 rows = B * S
 NAMES = {0: "X", 1: "H1", 2: "CTX", 3: "FF", 4: "T1", 5: "statsA", 6: "statsB", 7: "Q units", 8: "K units", 9: "V^T units"}
 def read(which):
@@ -25,13 +27,14 @@ def read(which):
         return (hv[:, 0] + hv[:, 1]).reshape(rows, -1)
     return out
 for layer in range(cfg.layers - 1):
-    for k, bufs in ((0, [0, 7, 8, 9]), (1, [2]), (2, [1]), (3, [3]), (4, [0, 4])):
+    for k, bufs in ((0, [0] if ATT else [0, 7, 8, 9]), (1, [2]), (2, [1]), (3, [3]), (4, [0, 4])):
         snap = {}
         for on in (0, 1):
-            e.set_mx(bool(on))
+            if ATT: e.set_mx(True); e.set_mx_attention(bool(on))
+            else: e.set_mx(bool(on)); e.set_mx_attention(False)
             e.L.glc_debug_set_stop(e.h, 10 * layer + k)
             e.forward(ids, mask)
-            assert e.last_group_split() and e.last_mx() == bool(on)
+            assert e.last_group_split() and e.last_mx() == (True if ATT else bool(on))
             snap[on] = {b: read(b) for b in bufs + ([6] if k == 2 else []) + ([5] if k == 4 else [])}
         for b in snap[0]:
             a0, a1 = snap[0][b], snap[1][b]

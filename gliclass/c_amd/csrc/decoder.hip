@@ -511,6 +511,23 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int a = 0; a < ND; ++a) store_acc32_wide<T>(o[a], inv, out + 32 * a, h);      // 16-byte stores via v_permlane32_swap (glc_common.h)
+    } else if (ctx_gs == 2) {
+        // GX context rows (glc_common.h; the A operand of the MX cross-term GEMM): as attention_wg.hip, one cross-half exchange per register
+        unsigned char* row = reinterpret_cast<unsigned char*>(CTX) + ((size_t)b * Sp + q0 + c) * 4 * ((size_t)nq * D);
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float own_a = o[a][8 * p + e] * inv, own_b = o[a][8 * p + 4 + e] * inv;
+                    const float got = __shfl_xor(h ? own_a : own_b, 32, 64);
+                    v[e] = h ? got : own_a;
+                    v[4 + e] = h ? own_b : got;
+                }
+                gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT));
+            }
     } else if (ctx_gs) {
         // group-split context rows: block a of this head is group hq * D/32 + a of the row; hi = f16(v), lo = f16(v - hi)
         f16_t* row = reinterpret_cast<f16_t*>(CTX) + ((size_t)b * Sp + q0 + c) * 2 * ((size_t)nq * D) + (size_t)(hq * (D / 32)) * 64;

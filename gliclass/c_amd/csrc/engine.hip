@@ -49,6 +49,8 @@ struct DecLayerW {                     // decoder-style backbone (decoder.hip)
     void *Wqkv = nullptr, *Wo = nullptr, *Wgu = nullptr, *Wd = nullptr;       // T: [(nq+2nkv)d, H], [H, nq d], [2I, H] (gate rows | up rows), [H, I]
     float *bqkv = nullptr, *ln1 = nullptr, *ln2 = nullptr;                    // f32
     void *Wqkvf = nullptr, *Wguf = nullptr;                                   // fp32 mode, RMSNorm folded into the GEMMs: Wqkv diag(ln1), Wgu diag(ln2), group-split
+    void *Wqkvf_x = nullptr, *Wo_x = nullptr, *Wguf_x = nullptr, *Wd_x = nullptr;   // MX pipeline: the same four as GX rows + their fp8 exponents
+    int ws_qkvf = 0, ws_o = 0, ws_guf = 0, ws_d = 0;
 };
 
 struct LayerW {
@@ -368,9 +370,14 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     const bool rnf = gs && e->ln_fused && e->fused_swiglu && L > 0 && e->dlayers[0].Wqkvf && e->dlayers[0].Wguf && e->statsA && e->statsB && e->ln_part;
     float2 *sX = e->statsA, *sXn = e->statsB;
     e->last_lnf = rnf;
+    // MX pipeline (round 3, as the encoder's): GX rows + gemm256x for the four projections of every layer; attention stays on split units
+    bool mx = rnf && e->mx && e->mx_built && e->prec_mask == 0;
+    for (int l = 0; mx && l < L; ++l) mx = e->dlayers[l].Wqkvf_x && e->dlayers[l].Wo_x && e->dlayers[l].Wguf_x && e->dlayers[l].Wd_x;
+    e->last_mx = mx;
+    auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* { return mx ? glc_launch_gemm256x(st, epi, ga) : glc_launch_gemm256s_gs(st, epi, ga); };
     if (rnf) {      // the embedding rows enter the pipeline: plain fp32 (X2) -> raw group-split rows (X) + statistics
         HIPCHK(hipMemcpyAsync(e->X2, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
-        KCHK(glc_launch_rows_to_gs_rms(st, (const float*)e->X2, e->X, sX, c.ln_eps, M, H), false);
+        KCHK(glc_launch_rows_to_gs_rms(st, (const float*)e->X2, e->X, sX, c.ln_eps, M, H, mx ? 1 : 0), false);
     }
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = e->dlayers[l];
@@ -379,16 +386,18 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         GemmArgs g;
         g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H; g.gs_c_plain = 1;
         if (rnf) { g.A = X; g.W = w.Wqkvf; g.a_stats = sX; }
-        { Prof p(e, PC_QKV); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
+        if (mx) { g.W = w.Wqkvf_x; g.mx_ws = w.ws_qkvf; }
+        { Prof p(e, PC_QKV); KCHK(gs ? gemm_gs(EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
           if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
           else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
         { Prof p(e, PC_ATTN);
-          if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal, gs ? 1 : 0), false);
+          if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal, mx ? 2 : (gs ? 1 : 0)), false);
           else KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ; o.gs_resid_plain = 1;
         if (rnf) { o.gs_resid_plain = 0; o.ln_part = e->ln_part; }        // raw group-split residual in, raw group-split sum + partials out
-        { Prof p(e, PC_ATTN_OUT); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }   // Q2:233, :291
+        if (mx) { o.W = w.Wo_x; o.mx_ws = w.ws_o; }
+        { Prof p(e, PC_ATTN_OUT); KCHK(gs ? gemm_gs(EPI_RESID, o) : launch_gemm_auto(e, dt, EPI_RESID, o), false); }   // Q2:233, :291
         std::swap(X, Xn); std::swap(sX, sXn);
         { Prof p(e, PC_LN); KCHK(rnf ? glc_launch_ln_stats(st, e->ln_part, H / 64, sX, M, H, c.ln_eps, 1)
                                  : gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln2, c.ln_eps, M, H)
@@ -396,8 +405,9 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
         if (rnf) { f1.A = X; f1.W = w.Wguf; f1.a_stats = sX; }
+        if (mx) { f1.W = w.Wguf_x; f1.mx_ws = w.ws_guf; }
         { Prof p(e, PC_FFN1);                                                                                                  // Q2:47 silu(gate) * up
-          if (e->fused_swiglu && gs) { f1.C = e->FF; KCHK(glc_launch_gemm256s_gs(st, EPI_SWIGLU, f1), false); }
+          if (e->fused_swiglu && gs) { f1.C = e->FF; KCHK(gemm_gs(EPI_SWIGLU, f1), false); }
           else if (e->fused_swiglu && dt == GLC_F32) {      // small forward of the fp32 mode: plain rows, interleaved [gate | up] columns
               KCHK(launch_gemm_auto(e, dt, EPI_BIAS, f1), false); KCHK(glc_launch_swiglu(st, dt, e->GU, e->FF, (size_t)M, I, 1), false); }
           else if (e->fused_swiglu) { f1.C = e->FF; KCHK(glc_launch_gemm256s(st, dt, EPI_SWIGLU, f1), false); }
@@ -406,7 +416,8 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         GemmArgs f2;
         f2.A = e->FF; f2.W = w.Wd; f2.bias = nullptr; f2.C = Xn; f2.resid = X; f2.Mpad = Mpad; f2.N = H; f2.K = I; f2.gs_resid_plain = 1;
         if (rnf) { f2.gs_resid_plain = 0; if (l + 1 < L) f2.ln_part = e->ln_part; }      // (the last layer hands plain fp32 rows to the final norm)
-        { Prof p(e, PC_FFN2); KCHK(gs ? glc_launch_gemm256s_gs(st, EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
+        if (mx) { f2.W = w.Wd_x; f2.mx_ws = w.ws_d; }
+        { Prof p(e, PC_FFN2); KCHK(gs ? gemm_gs(EPI_RESID, f2) : launch_gemm_auto(e, dt, EPI_RESID, f2), false); }
         std::swap(X, Xn); std::swap(sX, sXn);
         if (rnf && l + 1 < L) { Prof p(e, PC_LN); KCHK(glc_launch_ln_stats(st, e->ln_part, H / 64, sX, M, H, c.ln_eps, 1), false); }
         if (e->keep_hidden && l + 1 < L)
@@ -701,6 +712,21 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
                 if (!w.Wguf || !upload_as(e, wf.data(), 2 * (size_t)I * H, w.Wguf, staging)) { lok = false; break; }
                 pm = glc_launch_presplit(e->stream, w.Wguf, 2 * (size_t)I * H);
                 if (pm) { set_err(pm); lok = false; break; }
+                if (e->mx_built) {      // MX pipeline: the four projections once more as GX rows (fold_host still holds Wgu diag(ln2), interleaved)
+                    auto to_gx = [&](const float* src, size_t n, void*& dst, int& ws) -> bool {
+                        float mxv = 0.f;
+                        for (size_t i = 0; i < n; ++i) { const float a = fabsf(src[i]); mxv = a > mxv ? a : mxv; }
+                        ws = glc_gx_weight_exponent(mxv);
+                        dst = dmalloc(e, n * sizeof(float), false);
+                        if (!dst || !upload_as(e, src, n, dst, staging)) return false;
+                        const char* gm = glc_launch_to_gx(e->stream, dst, n, ws, 1);
+                        if (gm) { set_err(gm); return false; }
+                        return hipStreamSynchronize(e->stream) == hipSuccess;
+                    };
+                    if (!to_gx(wf.data(), 2 * (size_t)I * H, w.Wguf_x, w.ws_guf)) { lok = false; break; }
+                    fold_rows(t[1], NQ, t[0], wf.data()); fold_rows(t[3], NKV, t[0], wf.data() + NQ * H); fold_rows(t[5], NKV, t[0], wf.data() + (NQ + NKV) * H);
+                    if (!to_gx(wf.data(), NQKV * H, w.Wqkvf_x, w.ws_qkvf) || !to_gx(t[7], (size_t)H * NQ, w.Wo_x, w.ws_o) || !to_gx(t[11], (size_t)H * I, w.Wd_x, w.ws_d)) { lok = false; break; }
+                }
             }
             for (size_t i = 0; i < NQ; ++i) bqkv[i] = t[2][i];
             for (size_t i = 0; i < NKV; ++i) { bqkv[NQ + i] = t[4][i]; bqkv[NQ + NKV + i] = t[6][i]; }
@@ -806,7 +832,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     // everywhere (three f16 MFMAs per product, ~1e-5); GLICLASS_MX=build: GX weight copies built, pipeline off until glc_debug_set_mx.
     {
         const char* mv = getenv("GLICLASS_MX");
-        const bool eligible = dtype == GLC_F32 && !dec && e->w_presplit && e->attn_split && e->ln_fused && cfg->hidden % 256 == 0 && cfg->inter % 256 == 0 && cfg->layers >= 2;
+        const bool eligible = dec ? (dtype == GLC_F32 && e->w_presplit && e->dec_split && e->ln_fused && cfg->hidden % 256 == 0 && (2 * cfg->inter) % 256 == 0 && cfg->inter % 32 == 0)
+                                  : (dtype == GLC_F32 && e->w_presplit && e->attn_split && e->ln_fused && cfg->hidden % 256 == 0 && cfg->inter % 256 == 0 && cfg->layers >= 2);
         e->mx_built = eligible && !(mv && !strcmp(mv, "0"));
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
         if (const char* av = getenv("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch

@@ -227,7 +227,43 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
     float* stg = reinterpret_cast<float*>(smem256x + wave * EPI_PATCH);
     const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;
     constexpr float kHi = 1.0f, kLo = (float)(1 << GLC_GX_SHIFT), kInvLo = 1.0f / (float)(1 << GLC_GX_SHIFT);       // activation rows: exponent 0
-    if constexpr (!VMODE) {
+    if constexpr (EPI == EPI_SWIGLU) {
+        // W rows alternate 16 gate / 16 up features (engine.hip interleaves them at load): in D[n = 32 J + 8 q + 4 h + e][m] the register quads
+        // q = 0, 1 hold gate features 8 q + 4 h + e of block J and q + 2 the matching up features — same lane, no exchange.  The wave's
+        // 128 x 64 sub-tile becomes 128 x 32 outputs silu(gate) * up (Q2:47); patch [32 rows][32 features], row stride 36 floats.
+        // RMSNorm folded into this GEMM (a_stats: W holds W diag(gain), the rows are raw): gate and up scale by the row's rstd first.
+        const int Iw = N >> 1;
+        const bool lnf = p.a_stats != nullptr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float rs = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + c32].y : 1.0f;
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gt = acc[c][J][4 * q + e] * rs, up = acc[c][J][4 * (q + 2) + e] * rs;
+                        v[e] = gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
+                    }
+                    *reinterpret_cast<f32x4*>(stg + c32 * 36 + 16 * J + 8 * q + 4 * h) = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = lane + 64 * k, row = idx >> 2, g4 = idx & 3;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * 36 + g4 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 36 + g4 * 8 + 4);
+                const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int m = m0 + wm * 128 + c * 32 + row;
+                gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * Iw, (n0 >> 1) + wn * 32 + g4 * 8, v, kHi, kLo);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if constexpr (!VMODE) {
         // D[n = 32 J + 8 q + 4 h + e][m = 32 I + c32]; patch [32 rows m][64 cols n], row stride 68 floats
         const int which = (EPI == EPI_QKV) ? n0 / p.H : 0;
         const bool lnf = EPI != EPI_RESID && p.a_stats != nullptr;
@@ -484,7 +520,7 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
     if (!(a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 32 == 0)) return false;
     if (a.mx_ws < -40 || a.mx_ws > 60) return false;
     if (epi == EPI_QKV) return a.H % 256 == 0 && a.N == 3 * a.H && a.Sp % 64 == 0 && a.Sp >= 64 && a.nh * 64 == a.H;
-    return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID;
+    return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_SWIGLU;
 }
 
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a) {
@@ -498,6 +534,7 @@ const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a) {
         case EPI_BIAS: return launch_x<EPI_BIAS, false>(st, a, 0, ntn);
         case EPI_GELU: return launch_x<EPI_GELU, false>(st, a, 0, ntn);
         case EPI_RESID: return launch_x<EPI_RESID, false>(st, a, 0, ntn);
+        case EPI_SWIGLU: return a.bias ? "gemm256x: the SwiGLU epilogue takes no bias" : launch_x<EPI_SWIGLU, false>(st, a, 0, ntn);
         case EPI_QKV: {
             const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
             const char* m = launch_x<EPI_QKV, false>(st, a, nq, nqk - nq);

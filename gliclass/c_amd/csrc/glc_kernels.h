@@ -59,7 +59,7 @@ enum { PM_QKV_A = 1 << 0, PM_QKV_W = 1 << 1, PM_AO_A = 1 << 2, PM_AO_W = 1 << 3,
 // (sum, M2) partials of 64-column blocks [M][nparts] -> (mean, 1 / sqrt(var + eps)) [M] over rows of H = 64 nparts values (rows.hip; Chan's merge in double, fixed order)
 const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, float2* stats, int M, int H, float eps, int rms = 0);   // rms: (0, 1 / sqrt(E[x^2] + eps))
 // decoder backbone: plain fp32 rows -> raw group-split rows + RMSNorm statistics (0, rstd) per row
-const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H);
+const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H, int gx = 0);
 const char* glc_launch_gemm(hipStream_t st, int dtype, int epi, const GemmArgs& a);       // 128x128 tile, any T
 bool glc_gemm256_supported(int dtype, const GemmArgs& a);                                 // shapes the 256x256 LDS-DMA kernel takes (16-bit T)
 const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmArgs& a);   // 256x256 tile, staggered wave groups (gemm256s.hip)

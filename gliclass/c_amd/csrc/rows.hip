@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restri
     ln_row_wave_gs<false, GX>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
 }
 // decoder backbone, RMSNorm folded into the GEMMs: the embedding rows (plain fp32) enter the pipeline as raw group-split rows + (0, rstd)
+template <bool GX>
 __global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __rest
         const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-        gs_store8(y, ch * 8, v);
+        row_store8<GX>(y, ch * 8, v);
     }
     ss = wave_sum(ss);
     if (lane == 0) stats[row] = make_float2(0.f, rsqrtf(ss / (float)H + eps));
@@ -436,9 +437,10 @@ const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, 
     return nullptr;
 }
 
-const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H) {
+const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H, int gx) {
     if (!X || !Y || !stats || M <= 0 || H <= 0 || H % 32) return "rows_to_gs_rms: bad args";
-    hipLaunchKernelGGL(rows_to_gs_rms_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H);
+    if (gx) hipLaunchKernelGGL(rows_to_gs_rms_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H);
+    else hipLaunchKernelGGL(rows_to_gs_rms_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H);
     return nullptr;
 }
 

@@ -238,8 +238,9 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
             plain = eng.forward(ids, mask)
             assert not eng.last_group_split()
             eng.set_group_split(2)
+            eng.set_mx(False)                 # the split-f16 projections; the MX pipeline is checked at the end of the loop body
             gs = eng.forward(ids, mask)
-            assert eng.last_group_split()
+            assert eng.last_group_split() and not eng.last_mx()
             assert np.isfinite(gs).all()
             assert np.abs(sig(gs) - sig(ref)).max() <= TOL_PROB["f32"], (B, S)
             assert np.abs(sig(gs) - sig(plain)).max() <= 1e-4, (B, S)
@@ -253,6 +254,13 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
             assert np.abs(sig(gs) - sig(unf)).max() <= 1e-4, (B, S)
             if cfg.hidden % 256 == 0:
                 assert not np.array_equal(gs, unf), "the RMSNorm switch changed nothing: is the folded path running?"
+                # MX cross-term projections (round 3; the default of large decoder forwards too): GX rows + gemm256x incl. its SwiGLU epilogue
+                eng.set_mx(True)
+                mx = eng.forward(ids, mask)
+                assert eng.last_mx(), "the MX pipeline did not run"
+                assert np.isfinite(mx).all() and not np.array_equal(mx, gs)
+                assert np.abs(sig(mx) - sig(ref)).max() <= 3e-4, (B, S)
+                assert np.abs(sig(mx) - sig(gs)).max() <= 3e-4, (B, S)
     finally:
         eng.close()
 

@@ -22,6 +22,8 @@ def test_mx_gemm_every_epilogue_vs_split_gemm(mode, weights_for):
     out = (C.c_double * 5)()
     try:
         for (M, N, K, a_amp, w_amp) in ((256, 256, 32, 1.0, 0.05), (512, 768, 768, 2.0, 0.05), (1024, 768, 3072, 1.0, 0.1), (256, 768, 96, 50.0, 1.0)):
+            if mode == 4:
+                N = 768                      # N = 3 H, H = 256: a tile never straddles Q | K | V
             rc = eng.L.glc_debug_gemm_mx_check(eng.h, M, N, K, a_amp, w_amp, mode, out)
             assert rc == 0, eng.L.glc_last_error().decode()
             max_d, max_ref, rms_d, rms_ref, part_d = (out[i] for i in range(5))

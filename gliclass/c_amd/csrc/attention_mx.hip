@@ -61,7 +61,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 
 // ABL: timing-only builds (wrong results; AttnArgs::variant bits 8 / 9 through glc_debug_attn_bench): 1 = without the block-scaled MFMAs,
 // 2 = without the fp8 conversion of the probabilities.
-template <int ABL = 0>
+// DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them; the stamps
+// pin the instruction order at each boundary, so the stamped build is slower than the one it describes).
+template <int ABL = 0, bool DIAG = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -330,9 +332,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         if ((kt_a % NW) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
         int od_n = block_x(q0, kt_a + 1);
         int odx_n = block_x(QX, kt_a + 1);
+        unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0, tlast = 0;
+        const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
+        auto stamp = [&](int k) __attribute__((always_inline)) {      // time since the previous stamp goes to segment k (k < 0: start)
+            if constexpr (DIAG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (k >= 0) seg[k] += t - tlast;
+                tlast = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
             const bool extra = (kt % NW) == wave;               // wave-uniform: this wave also computes the block nobody owns
+            stamp(-1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // everything requested during tile kt - 1 (rows, offsets, my DMA pieces of tile kt + 1)
+            stamp(0);                                           // seg 0: wait for last tile's requests
             MxFrag pk;
             const int od = od_n, odx = odx_n;
             od_n = block_x(q0, kt + 2);
@@ -358,16 +373,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             // ---- S^T = K Q^T + c2p ----
             mm_lh_hl(kf, qf, sacc);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(1);                                           // seg 1: K fragments, c2p gather, p2c + S^T MFMA issue
             if (((kt + 1) % NW) == wave) load_rows(PQg, odx, pqx);
             __builtin_amdgcn_sched_barrier(0);
             load_rows(PKg, pk_of_pq(od), pk);
             __builtin_amdgcn_sched_barrier(0);
             load_rows(PQg, od, pq);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(2);                                           // seg 2: row requests (8 waves x 16-24 KB through the CU's vector-memory path)
             wg_barrier_lds();                                   // X: every wave has finished gathering the previous tile's image
+            stamp(3);                                           // seg 3: barrier X
             band_store(img + c * LROWP + 32 * wave, bacc);
             if (extra) band_store(img + c * LROWP + 32 * NW, bacc2);
             wg_barrier_lds();                                   // Y: image complete; tile kt + 1 is in the ring for everyone
+            stamp(4);                                           // seg 4: image stores (wait for the p2c MFMA results) + barrier Y
             dma_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);
             __builtin_amdgcn_sched_barrier(0);
             float sv[16];
@@ -380,15 +399,28 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             f32x16 cacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
+            stamp(5);                                           // seg 5: DMA request, image gather (waits for S^T)
             mm_lh_hl(pk, qf, cacc);                             // c2p of L(kt + 1)  [rr][query c]
             softmax_pv(sv, kt);
+            stamp(6);                                           // seg 6: c2p MFMA issue, softmax, P.V issue
             band_store(c2p_l + c * LROW + (xr ^ 32), cacc);
+            stamp(7);                                           // seg 7: c2p block store (waits for the matrix pipe to drain)
+            if constexpr (DIAG) ++tiles;
         };
         for (int kt = kt_a;;) {
             band_tile(kt, 0);
             if (++kt >= kt_b) break;
             band_tile(kt, 32);
             if (++kt >= kt_b) break;
+        }
+        if constexpr (DIAG) {
+            if (a.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {     // 64 workgroups of XCD 0
+                unsigned long long* o = a.stamps + ((size_t)(blockIdx.x >> 3) * NW + wave) * 10;
+                for (int k = 0; k < 8; ++k) o[k] = seg[k];
+                // s_memtime ticks per 100 MHz s_memrealtime tick over the band loop, x1000 (the clock s_memtime counts, in 0.1 MHz)
+                const unsigned long long dc = __builtin_amdgcn_s_memtime() - clk0, dr = __builtin_amdgcn_s_memrealtime() - rt0;
+                o[8] = dr ? dc * 1000 / dr : 0; o[9] = tiles;
+            }
         }
     }
 
@@ -457,19 +489,16 @@ const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a) {
     constexpr size_t lds = mx_lds_bytes();
     static_assert(lds <= 160 * 1024, "LDS budget");
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
-    if (a.variant & 256) {
-        static std::atomic<unsigned> r1{0};
-        if (!glc_raise_lds_limit(attn_mx_kernel<1>, (int)lds, r1)) return "attention(mx): cannot raise the dynamic LDS limit";
-        hipLaunchKernelGGL(attn_mx_kernel<1>, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
-    } else if (a.variant & 512) {
-        static std::atomic<unsigned> r2{0};
-        if (!glc_raise_lds_limit(attn_mx_kernel<2>, (int)lds, r2)) return "attention(mx): cannot raise the dynamic LDS limit";
-        hipLaunchKernelGGL(attn_mx_kernel<2>, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
-    } else {
-        if (!glc_raise_lds_limit(attn_mx_kernel<0>, (int)lds, raised)) return "attention(mx): cannot raise the dynamic LDS limit";
-        hipLaunchKernelGGL(attn_mx_kernel<0>, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
-    }
-    return nullptr;
+    auto go = [&](auto kern, std::atomic<unsigned>& r) -> const char* {
+        if (!glc_raise_lds_limit(kern, (int)lds, r)) return "attention(mx): cannot raise the dynamic LDS limit";
+        hipLaunchKernelGGL(kern, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
+        return nullptr;
+    };
+    static std::atomic<unsigned> r1{0}, r2{0}, r4{0};
+    if (a.stamps) return go(attn_mx_kernel<0, true>, r4);
+    if (a.variant & 256) return go(attn_mx_kernel<1>, r1);
+    if (a.variant & 512) return go(attn_mx_kernel<2>, r2);
+    return go(attn_mx_kernel<0>, raised);
 }
 
 // nrows rows (a multiple of 32) x 64 columns x nheads tensors in split units -> MX tiles (position tables at load)

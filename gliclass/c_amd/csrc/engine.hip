@@ -1608,6 +1608,28 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
             (void)hipFree(dbuf);
         }
     }
+    if (stamps && mxk) {       // the MX-tile kernel, stamped build: 64 workgroups x 8 waves x 10 counters
+        unsigned long long* dbuf = nullptr;
+        const size_t ns = 64 * 8 * 10;
+        if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
+            AttnArgs as = a; as.stamps = dbuf;
+            const char* m = glc_launch_attention_mx(st, as);
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> hs(ns);
+            if (!m && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double s[10] = {0};
+                for (size_t i = 0; i < 64 * 8; ++i) for (int k = 0; k < 10; ++k) s[k] += (double)hs[i * 10 + k];
+                const double nt = s[9] > 0 ? s[9] : 1;
+                double tot = 0;
+                for (int k = 0; k < 8; ++k) tot += s[k];
+                fprintf(stderr, "[attn_mx stamps] per band tile per wave (s_memtime ticks), %.0f tiles: request wait %.0f | K + c2p gather + p2c/S issue %.0f | row requests %.0f | "
+                                "barrier X %.0f | image stores + barrier Y %.0f | DMA + image gather %.0f | c2p issue + softmax + P.V %.0f | c2p store %.0f | total %.0f | s_memtime clock %.0f MHz\n",
+                        nt, s[0] / nt, s[1] / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, s[6] / nt, s[7] / nt, tot / nt, s[8] / (64 * 8) / 10.0);
+            } else if (m) fprintf(stderr, "[attn_mx stamps] %s\n", m);
+            (void)hipFree(dbuf);
+        }
+    }
     if (stamps && !wg && !sp) {
         unsigned long long* dbuf = nullptr;
         const size_t ns = 64 * 4 * 8;

@@ -31,7 +31,7 @@ for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive
         a = acc[n][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, cs in acc.items():
-    if not any(t in k for t in ("attn_band", "attn_wg", "gemm256")): continue
+    if not any(t in k for t in ("attn_band", "attn_wg", "attn_mx", "gemm256")): continue
     print("==", k)
     for c, (tot, n) in sorted(cs.items()):
         print(f"   {c:34s} avg/launch = {tot/n:16.0f}")

@@ -11,6 +11,10 @@ from dataclasses import dataclass, asdict
 # scorer / pooling enums shared with include/gliclass_hip.h
 POOL_FIRST, POOL_AVG, POOL_LAST = 0, 1, 2
 SCORER_DOT = 0
+SCORER_WEIGHTED_DOT = 1
+SCORER_MLP = 2
+SCORER_MLP_HIDDEN = 256
+SCORER_NAMES = {"simple": SCORER_DOT, "weighted-dot": SCORER_WEIGHTED_DOT, "mlp": SCORER_MLP}
 BACKBONE_DEBERTA, BACKBONE_DECODER = 0, 1
 
 

@@ -103,6 +103,8 @@ struct glc_engine {
     void *QKV = nullptr, *GU = nullptr, *X2 = nullptr;                // decoder workspace: fused QKV rows, [gate|up] rows, second residual buffer
     bool fused_swiglu = false;                                        // Wgu rows interleaved 16 gate / 16 up: SwiGLU runs in the GEMM epilogue
     float* headw[8] = {nullptr};
+    float* scw[8] = {nullptr};           // the scorer's own tensors (weighted-dot: 8, mlp: 6, simple: none), fp32
+    float* scorer_ws = nullptr;          // its row buffers
     int P = 0;
     // workspace
     int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0, capSel = 0;
@@ -251,6 +253,11 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     if (hr > e->capHeadRows) {
         float** bufs[] = {&e->Gt, &e->G1t, &e->G2t};
         for (float** b : bufs) { dfree(e, *b); *b = (float*)dmalloc(e, (size_t)hr * c.hidden * sizeof(float)); if (!*b) return false; }
+        if (c.scorer != GLC_SCORER_DOT) {      // weighted-dot: [hr, 2H] + [rc, 3H] + [rc, 4H]; mlp: [rc, 2H] + [rc, 256] + [rc, 128] (rc <= hr)
+            dfree(e, e->scorer_ws);
+            e->scorer_ws = (float*)dmalloc(e, (size_t)hr * (9 * (size_t)c.hidden + 2 * GLC_SCORER_MLP_HIDDEN) * sizeof(float));
+            if (!e->scorer_ws) return false;
+        }
         e->capHeadRows = hr;
     }
     if (dec) {
@@ -317,6 +324,30 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     return true;
 }
 
+// the scorer's tensors (after the 8 projector tensors): matrices that a GEMM reads are pre-split like the projectors', the last Linear
+// (out features 1) stays a plain vector
+bool upload_scorer(glc_engine* e, const float* const* t) {
+    const int H = e->cfg.hidden, Mh = GLC_SCORER_MLP_HIDDEN;
+    size_t n[8] = {0};
+    bool mat[8] = {false};
+    int cnt = 0;
+    if (e->cfg.scorer == GLC_SCORER_WEIGHTED_DOT) {
+        const size_t v[8] = {2 * (size_t)H * H, 2 * (size_t)H, 2 * (size_t)H * H, 2 * (size_t)H, 12 * (size_t)H * H, 4 * (size_t)H, 4 * (size_t)H, 1};
+        for (int i = 0; i < 8; ++i) n[i] = v[i];
+        mat[0] = mat[2] = mat[4] = true; cnt = 8;
+    } else if (e->cfg.scorer == GLC_SCORER_MLP) {
+        const size_t v[6] = {(size_t)Mh * 2 * H, (size_t)Mh, (size_t)Mh / 2 * Mh, (size_t)Mh / 2, (size_t)Mh / 2, 1};
+        for (int i = 0; i < 6; ++i) n[i] = v[i];
+        mat[0] = mat[2] = true; cnt = 6;
+    }
+    for (int i = 0; i < cnt; ++i) {
+        e->scw[i] = upload_f32(e, t[i], n[i]);
+        if (!e->scw[i]) return false;
+        if (mat[i] && e->w_presplit) { const char* pm = glc_launch_presplit(e->stream, e->scw[i], n[i]); if (pm) { set_err(pm); return false; } }
+    }
+    return true;
+}
+
 // GEMM launches of the forward carry the engine's split-K workspace (used only when a shape has too few tiles, gemm.hip)
 static bool presplit_weight(const glc_engine* e, int dt, const void* W) {
     if (!e->w_presplit || dt != GLC_F32) return false;
@@ -329,6 +360,54 @@ const char* launch_gemm_auto(glc_engine* e, int dt, int epi, GemmArgs a) {
 const char* launch_gemm128(glc_engine* e, int dt, int epi, GemmArgs a) {
     a.ws = e->splitk_ws; a.ws_bytes = e->splitk_ws_bytes; a.w_presplit = presplit_weight(e, dt, a.W);
     return glc_launch_gemm(e->stream, dt, epi, a);
+}
+
+// The head after the row gather: the two FeaturesProjectors (Linear -> GELU -> Linear; text rows [0, rt) and class rows [rt, rt + rc)
+// share one fp32 buffer, one two-group GEMM per stage), then the scorer (include/gliclass_hip.h).
+bool run_head_tail(glc_engine* e, int B, int C, float* d_logits) {
+    const glc_model_config& c = e->cfg;
+    const int H = c.hidden;
+    hipStream_t st = e->stream;
+    const int rt = round_up(B, 128), rc = round_up(B * C, 128);
+    GemmArgs h;
+    h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
+    h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
+    KCHK(launch_gemm128(e, GLC_F32, EPI_GELU, h), false);
+    h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
+    KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, h), false);
+    const float* Tt = e->G2t;
+    const float* Cc = e->G2t + (size_t)rt * H;
+    if (c.scorer == GLC_SCORER_DOT) {
+        KCHK(glc_launch_head_score(st, Tt, Cc, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
+    } else if (c.scorer == GLC_SCORER_WEIGHTED_DOT) {
+        float* S1 = e->scorer_ws;                                // [rt + rc, 2H]: proj_text on the text rows, proj_label on the class rows
+        float* cat = S1 + (size_t)(rt + rc) * 2 * H;             // [rc, 3H]
+        float* hid = cat + (size_t)rc * 3 * H;                   // [rc, 4H]
+        GemmArgs g;
+        g.N = 2 * H; g.K = H; g.Mpad = rt + rc; g.m_split = rt;
+        g.A = e->G2t; g.W = e->scw[0]; g.bias = e->scw[1]; g.W2 = e->scw[2]; g.bias2 = e->scw[3]; g.C = S1;
+        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, g), false);
+        KCHK(glc_launch_scorer_wd_cat(st, S1, S1 + (size_t)rt * 2 * H, cat, B, C, H), false);
+        GemmArgs o;
+        o.N = 4 * H; o.K = 3 * H; o.Mpad = rc; o.A = cat; o.W = e->scw[4]; o.bias = e->scw[5]; o.C = hid;
+        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, o), false);
+        KCHK(glc_launch_relu_dot(st, hid, e->scw[6], e->scw[7], d_logits, B * C, 4 * H), false);
+    } else {
+        const int Mh = GLC_SCORER_MLP_HIDDEN;
+        float* pair = e->scorer_ws;                              // [rc, 2H] = [text | class]
+        float* h1 = pair + (size_t)rc * 2 * H;                   // [rc, 256]
+        float* h2 = h1 + (size_t)rc * Mh;                        // [rc, 128]
+        KCHK(glc_launch_scorer_pair(st, Tt, Cc, pair, B, C, H), false);
+        GemmArgs g;
+        g.N = Mh; g.K = 2 * H; g.Mpad = rc; g.A = pair; g.W = e->scw[0]; g.bias = e->scw[1]; g.C = h1;
+        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, g), false);
+        KCHK(glc_launch_relu(st, h1, (size_t)rc * Mh), false);
+        GemmArgs g2;
+        g2.N = Mh / 2; g2.K = Mh; g2.Mpad = rc; g2.A = h1; g2.W = e->scw[2]; g2.bias = e->scw[3]; g2.C = h2;
+        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, g2), false);
+        KCHK(glc_launch_relu_dot(st, h2, e->scw[4], e->scw[5], d_logits, B * C, Mh / 2), false);
+    }
+    return true;
 }
 
 // Decoder-style backbone: one launch sequence per batch (Q2:384-398).  Pre-norm residual stream X (operand type T).
@@ -430,14 +509,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         float* Gc = e->Gt + (size_t)round_up(B, 128) * H;
         KCHK(glc_launch_head_gather(st, dt, e->H1, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C, c.pooling == GLC_POOL_LAST ? e->klen : nullptr), false);
         if (c.pooling == GLC_POOL_AVG) KCHK(glc_launch_pool_avg(st, dt, e->H1, e->kbias, e->Gt, B, Sp, H), false);
-        const int rt = round_up(B, 128), rc = round_up(B * C, 128);
-        GemmArgs h;
-        h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
-        h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
-        KCHK(launch_gemm128(e, GLC_F32, EPI_GELU, h), false);
-        h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
-        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, h), false);
-        KCHK(glc_launch_head_score(st, e->G2t, e->G2t + (size_t)rt * H, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
+        if (!run_head_tail(e, B, C, d_logits)) return false;
     }
     HIPCHK(hipGetLastError(), false);
     e->lastB = B; e->lastS = S; e->lastSp = Sp;
@@ -624,15 +696,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
             KCHK(glc_launch_head_gather(st, dt, e->X, e->cls_pos, ccap, e->Gt, Gc, B, Sp, H, C, c.pooling == GLC_POOL_LAST ? e->klen : nullptr), false);
             if (c.pooling == GLC_POOL_AVG) KCHK(glc_launch_pool_avg(st, dt, e->X, e->kbias, e->Gt, B, Sp, H), false);
         }
-        // text rows [0, rt) and class rows [rt, rt + rc) share one fp32 buffer; one two-group GEMM per projector stage
-        const int rt = round_up(B, 128), rc = round_up(B * C, 128);
-        GemmArgs h;
-        h.N = H; h.K = H; h.Mpad = rt + rc; h.m_split = rt;
-        h.A = e->Gt; h.W = e->headw[0]; h.bias = e->headw[1]; h.W2 = e->headw[4]; h.bias2 = e->headw[5]; h.C = e->G1t;
-        KCHK(launch_gemm128(e, GLC_F32, EPI_GELU, h), false);
-        h.A = e->G1t; h.W = e->headw[2]; h.bias = e->headw[3]; h.W2 = e->headw[6]; h.bias2 = e->headw[7]; h.C = e->G2t;
-        KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, h), false);
-        KCHK(glc_launch_head_score(st, e->G2t, e->G2t + (size_t)rt * H, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
+        if (!run_head_tail(e, B, C, d_logits)) return false;
     }
     HIPCHK(hipGetLastError(), false);
     e->lastB = B; e->lastS = S; e->lastSp = Sp;
@@ -744,6 +808,7 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
             e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr;
             if (hok && (i % 2 == 0) && e->w_presplit) { const char* pm = glc_launch_presplit(e->stream, e->headw[i], (size_t)H * H); if (pm) { set_err(pm); hok = false; } }
         }
+        hok = hok && upload_scorer(e, ht + GLC_TENSORS_HEAD);
         if (!hok) break;
         if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err(std::string("engine_create: ") + hipGetErrorString(hipGetLastError())); break; }
         ok = true;
@@ -810,8 +875,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         set_err("engine_create: decoder backbone needs head_dim 64 or 128, heads % kv_heads == 0 and rope_theta > 1"); return nullptr;
     }
     if (cfg->hidden % 128 || cfg->inter % 128) { set_err("engine_create: hidden and intermediate sizes must be multiples of 128"); return nullptr; }
-    if (cfg->pooling < GLC_POOL_FIRST || cfg->pooling > GLC_POOL_LAST || cfg->scorer != GLC_SCORER_DOT) {
-        set_err("engine_create: pooling must be 'first', 'avg' or 'last' and the scorer 'simple' (other upstream scorers are not implemented)"); return nullptr;
+    if (cfg->pooling < GLC_POOL_FIRST || cfg->pooling > GLC_POOL_LAST || cfg->scorer < GLC_SCORER_DOT || cfg->scorer > GLC_SCORER_MLP) {
+        set_err("engine_create: pooling must be 'first', 'avg' or 'last' and the scorer 'simple', 'weighted-dot' or 'mlp'"); return nullptr;
     }
     int ndev = glc_device_count();
     if (ndev <= 0) { set_err("engine_create: no HIP device visible (this engine has no CPU path)"); return nullptr; }
@@ -1011,6 +1076,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             e->headw[i] = upload_f32(e, ht[i], (i % 2 == 0) ? (size_t)H * H : (size_t)H); hok = e->headw[i] != nullptr;
             if (hok && (i % 2 == 0) && e->w_presplit) { const char* pm = glc_launch_presplit(e->stream, e->headw[i], (size_t)H * H); if (pm) { set_err(pm); hok = false; } }
         }
+        hok = hok && upload_scorer(e, ht + GLC_TENSORS_HEAD);
         if (!hok) { fail(); break; }
         if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err(std::string("engine_create: ") + hipGetErrorString(hipGetLastError())); fail(); break; }
         (void)hipFree(staging);

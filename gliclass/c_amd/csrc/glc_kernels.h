@@ -189,6 +189,11 @@ const char* glc_launch_pool_avg(hipStream_t st, int dtype, const void* X, const 
 // logits[b*C+j] = <Tt[b], Cc[b*C+j]> (* logit_scale when normalised)
 const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* Cc, float* logits, int B, int C, int H,
                                   int normalize, float logit_scale);
+// scorers 'weighted-dot' / 'mlp' (include/gliclass_hip.h): row shuffles between the head's GEMMs and the closing ReLU -> Linear(K, 1)
+const char* glc_launch_scorer_wd_cat(hipStream_t st, const float* St, const float* Sc, float* cat, int B, int C, int H);
+const char* glc_launch_scorer_pair(hipStream_t st, const float* Tt, const float* Cc, float* out, int B, int C, int H);
+const char* glc_launch_relu(hipStream_t st, float* x, size_t n);
+const char* glc_launch_relu_dot(hipStream_t st, const float* X, const float* w, const float* bias, float* logits, int rows, int K);
 
 // Pruned last layer: compact the rows the head reads. Row r < B: [CLS] of sequence r; row B + b*C + j: class
 // token j of sequence b (sequence start if absent). Writes Xs[r,:] = X[row,:] and the (sequence, position) lists.

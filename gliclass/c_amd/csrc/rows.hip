@@ -379,6 +379,41 @@ __global__ __launch_bounds__(256) void head_score_kernel(const float* __restrict
     if (lane == 0) logits[idx] = dot;
 }
 
+// ---- scorers other than 'simple' (include/gliclass_hip.h): row shuffles and the last Linear(., 1); their GEMMs are the head's ----
+// weighted-dot: cat[b*C + j] = [t1(b), c1(b,j), t2(b) * c2(b,j)]  with (t1|t2) = St[b] and (c1|c2) = Sc[b*C + j], rows of 2H
+__global__ __launch_bounds__(256) void scorer_wd_cat_kernel(const float* __restrict__ St, const float* __restrict__ Sc, float* __restrict__ cat,
+                                                            int B, int C, int H) {
+    const int r = blockIdx.x;
+    const float* t = St + (size_t)(r / C) * 2 * H;
+    const float* c = Sc + (size_t)r * 2 * H;
+    float* o = cat + (size_t)r * 3 * H;
+    for (int i = threadIdx.x; i < H; i += 256) { o[i] = t[i]; o[H + i] = c[i]; o[2 * H + i] = t[H + i] * c[H + i]; }
+}
+// mlp: pair[b*C + j] = [text(b), class(b,j)]
+__global__ __launch_bounds__(256) void scorer_pair_kernel(const float* __restrict__ Tt, const float* __restrict__ Cc, float* __restrict__ out,
+                                                          int B, int C, int H) {
+    const int r = blockIdx.x;
+    const float* t = Tt + (size_t)(r / C) * H;
+    const float* c = Cc + (size_t)r * H;
+    float* o = out + (size_t)r * 2 * H;
+    for (int i = threadIdx.x; i < H; i += 256) { o[i] = t[i]; o[H + i] = c[i]; }
+}
+__global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = fmaxf(x[i], 0.f);
+}
+// logits[r] = sum_k relu(X[r][k]) * w[k] + bias[0]   (ReLU -> Linear(K, 1)); one wave per row
+__global__ __launch_bounds__(256) void relu_dot_kernel(const float* __restrict__ X, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ logits, int rows, int K) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = X + (size_t)r * K;
+    float a = 0.f;
+    for (int i = lane; i < K; i += 64) a += fmaxf(x[i], 0.f) * w[i];
+    a = wave_sum(a);
+    if (lane == 0) logits[r] = a + bias[0];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (T)src[i];
@@ -517,6 +552,27 @@ const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* 
                                   int normalize, float logit_scale) {
     if (B <= 0 || C <= 0 || !Tt || !Cc || !logits) return "head_score: bad args";
     hipLaunchKernelGGL(head_score_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, Tt, Cc, logits, B, C, H, normalize, logit_scale);
+    return nullptr;
+}
+
+const char* glc_launch_scorer_wd_cat(hipStream_t st, const float* St, const float* Sc, float* cat, int B, int C, int H) {
+    if (B <= 0 || C <= 0 || H <= 0 || !St || !Sc || !cat) return "scorer_wd_cat: bad args";
+    hipLaunchKernelGGL(scorer_wd_cat_kernel, dim3(B * C), dim3(256), 0, st, St, Sc, cat, B, C, H);
+    return nullptr;
+}
+const char* glc_launch_scorer_pair(hipStream_t st, const float* Tt, const float* Cc, float* out, int B, int C, int H) {
+    if (B <= 0 || C <= 0 || H <= 0 || !Tt || !Cc || !out) return "scorer_pair: bad args";
+    hipLaunchKernelGGL(scorer_pair_kernel, dim3(B * C), dim3(256), 0, st, Tt, Cc, out, B, C, H);
+    return nullptr;
+}
+const char* glc_launch_relu(hipStream_t st, float* x, size_t n) {
+    if (!x) return "relu: null";
+    if (n) hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, x, n);
+    return nullptr;
+}
+const char* glc_launch_relu_dot(hipStream_t st, const float* X, const float* w, const float* bias, float* logits, int rows, int K) {
+    if (rows <= 0 || K <= 0 || !X || !w || !bias || !logits) return "relu_dot: bad args";
+    hipLaunchKernelGGL(relu_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, w, bias, logits, rows, K);
     return nullptr;
 }
 

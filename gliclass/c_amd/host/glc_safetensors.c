@@ -76,7 +76,13 @@ static int parse_config(const gj_value* root, glc_model_config* c) {
     if (arch && strcmp(arch, "uni-encoder")) REJECT("architecture_type '%s' is not implemented (only uni-encoder)", arch);
     if (jflag(root, "use_lstm", 0)) REJECT("use_lstm=true is not implemented");
     const char* scorer = jtext(root, "scorer_type");
-    if (scorer && strcmp(scorer, "simple")) REJECT("scorer_type '%s' is not implemented (only 'simple')", scorer);
+    int scorer_id = GLC_SCORER_DOT;
+    if (scorer) {
+        if (!strcmp(scorer, "simple")) scorer_id = GLC_SCORER_DOT;
+        else if (!strcmp(scorer, "weighted-dot")) scorer_id = GLC_SCORER_WEIGHTED_DOT;
+        else if (!strcmp(scorer, "mlp")) scorer_id = GLC_SCORER_MLP;
+        else REJECT("scorer_type '%s' is not implemented (simple, weighted-dot, mlp)", scorer);
+    }
     const char* pool = jtext(root, "pooling_strategy");
     c->pooling = GLC_POOL_FIRST;
     if (pool) {
@@ -85,7 +91,7 @@ static int parse_config(const gj_value* root, glc_model_config* c) {
         else if (!strcmp(pool, "last")) c->pooling = GLC_POOL_LAST;
         else REJECT("pooling_strategy '%s' is not implemented (first, avg, last)", pool);
     }
-    c->scorer = GLC_SCORER_DOT;
+    c->scorer = scorer_id;
     c->embed_class_token = jflag(root, "embed_class_token", 1);
     c->normalize_features = jflag(root, "normalize_features", 0);
     c->logit_scale = (float)jnum(root, "logit_scale", 1.0);

@@ -1,6 +1,6 @@
 /*
  * Weight source for create_ort_session(): reads a .glcw blob (written by gliclass/c_amd/weights.py)
- * or synthesises a model from "synthetic:<config>[:seed]".  Stands in for the ONNX file load inside
+ * or synthesises a model from "synthetic:<config>[:seed[:scorer]]".  Stands in for the ONNX file load inside
  * g_ort->CreateSession (/root/reference/src/model.c:269, path from /root/reference/include/paths.h:5).
  */
 #include "glc_weights.h"
@@ -78,6 +78,50 @@ int glc_named_config(const char* name, glc_model_config* c) {
 
 static double lin_amp(double t, double fan_in) { return sqrt(3.0) * t / sqrt(fan_in); }
 
+/* the head's tensors (index k inside the head): the two FeaturesProjectors, then the scorer's own (include/gliclass_hip.h) */
+static int head_spec(const glc_model_config* c, int k, char* name, uint64_t shape[4], double* amp, double* mean) {
+    const uint64_t H = (uint64_t)c->hidden;
+    char buf[96];
+#define SPEC1(nm, n0, a, m) do { snprintf(name, 96, "%s", nm); shape[0] = (n0); *amp = (a); *mean = (m); return 1; } while (0)
+#define SPEC2(nm, n0, n1, a) do { snprintf(name, 96, "%s", nm); shape[0] = (n0); shape[1] = (n1); *amp = (a); return 2; } while (0)
+    if (k < 0 || k >= GLC_TENSORS_HEAD + glc_num_scorer_tensors(c->scorer)) return -1;
+    if (k < GLC_TENSORS_HEAD) {
+        const double t2 = sqrt(1.5 / sqrt((double)H)) / 0.7;
+        snprintf(buf, sizeof buf, "%s.linear_%d.%s", k < 4 ? "text_projector" : "classes_projector", (k % 4) / 2 + 1,
+                 (k % 2) ? "bias" : "weight");
+        switch (k % 4) {
+            case 0: SPEC2(buf, H, H, lin_amp(1.0, (double)H));
+            case 1: SPEC1(buf, H, 0.1, 0.0);
+            case 2: SPEC2(buf, H, H, lin_amp(t2, (double)H));
+            default: SPEC1(buf, H, 0.02, 0.0);
+        }
+    }
+    const int j = k - GLC_TENSORS_HEAD;
+    if (c->scorer == GLC_SCORER_WEIGHTED_DOT) {
+        switch (j) {
+            case 0: SPEC2("scorer.proj_text.weight", 2 * H, H, lin_amp(1.0, (double)H));
+            case 1: SPEC1("scorer.proj_text.bias", 2 * H, 0.05, 0.0);
+            case 2: SPEC2("scorer.proj_label.weight", 2 * H, H, lin_amp(1.0, (double)H));
+            case 3: SPEC1("scorer.proj_label.bias", 2 * H, 0.05, 0.0);
+            case 4: SPEC2("scorer.out_mlp.0.weight", 4 * H, 3 * H, lin_amp(1.0, (double)(3 * H)));
+            case 5: SPEC1("scorer.out_mlp.0.bias", 4 * H, 0.05, 0.0);
+            case 6: SPEC2("scorer.out_mlp.3.weight", 1, 4 * H, lin_amp(2.0, (double)(4 * H)));
+            default: SPEC1("scorer.out_mlp.3.bias", 1, 0.1, 0.0);
+        }
+    }
+    const uint64_t Mh = GLC_SCORER_MLP_HIDDEN;
+    switch (j) {
+        case 0: SPEC2("scorer.mlp.0.weight", Mh, 2 * H, lin_amp(1.0, (double)(2 * H)));
+        case 1: SPEC1("scorer.mlp.0.bias", Mh, 0.05, 0.0);
+        case 2: SPEC2("scorer.mlp.2.weight", Mh / 2, Mh, lin_amp(1.5, (double)Mh));
+        case 3: SPEC1("scorer.mlp.2.bias", Mh / 2, 0.05, 0.0);
+        case 4: SPEC2("scorer.mlp.4.weight", 1, Mh / 2, lin_amp(3.0, (double)(Mh / 2)));
+        default: SPEC1("scorer.mlp.4.bias", 1, 0.1, 0.0);
+    }
+#undef SPEC1
+#undef SPEC2
+}
+
 int glc_tensor_spec(const glc_model_config* c, int i, char* name, uint64_t shape[4], double* amp, double* mean) {
     const uint64_t H = (uint64_t)c->hidden, I = (uint64_t)c->inter;
     const uint64_t P = 2ull * (uint64_t)(c->pos_buckets > 0 ? c->pos_buckets : c->max_rel_pos);
@@ -111,17 +155,7 @@ int glc_tensor_spec(const glc_model_config* c, int i, char* name, uint64_t shape
             }
         }
         if (i == 1 + nl) SPEC1("norm.weight", H, 0.2, 1.0);
-        const int k = i - 2 - nl;
-        if (k < 0 || k >= GLC_TENSORS_HEAD) return -1;
-        const double t2 = sqrt(1.5 / sqrt((double)H)) / 0.7;
-        snprintf(buf, sizeof buf, "%s.linear_%d.%s", k < 4 ? "text_projector" : "classes_projector", (k % 4) / 2 + 1,
-                 (k % 2) ? "bias" : "weight");
-        switch (k % 4) {
-            case 0: SPEC2(buf, H, H, lin_amp(1.0, (double)H));
-            case 1: SPEC1(buf, H, 0.1, 0.0);
-            case 2: SPEC2(buf, H, H, lin_amp(t2, (double)H));
-            default: SPEC1(buf, H, 0.02, 0.0);
-        }
+        return head_spec(c, i - 2 - nl, name, shape, amp, mean);
     }
     switch (i) {
         case 0: SPEC2("embeddings.word_embeddings.weight", (uint64_t)c->vocab, H, 1.0);
@@ -153,17 +187,7 @@ int glc_tensor_spec(const glc_model_config* c, int i, char* name, uint64_t shape
             default: SPEC1(buf, H, 0.1, 0.0);
         }
     }
-    const int k = i - GLC_TENSORS_FIXED - nl;
-    if (k < 0 || k >= GLC_TENSORS_HEAD) return -1;
-    const double t2 = sqrt(1.5 / sqrt((double)H)) / 0.7;
-    snprintf(buf, sizeof buf, "%s.linear_%d.%s", k < 4 ? "text_projector" : "classes_projector", (k % 4) / 2 + 1,
-             (k % 2) ? "bias" : "weight");
-    switch (k % 4) {
-        case 0: SPEC2(buf, H, H, lin_amp(1.0, (double)H));
-        case 1: SPEC1(buf, H, 0.1, 0.0);
-        case 2: SPEC2(buf, H, H, lin_amp(t2, (double)H));
-        default: SPEC1(buf, H, 0.02, 0.0);
-    }
+    return head_spec(c, i - GLC_TENSORS_FIXED - nl, name, shape, amp, mean);
 #undef SPEC1
 #undef SPEC2
 }
@@ -177,8 +201,15 @@ static int load_synthetic(const char* spec, glc_weights* w) {
     if (nlen == 0 || nlen >= sizeof name) { fprintf(stderr, "Error: bad synthetic model spec '%s'\n", spec); return -1; }
     memcpy(name, p, nlen);
     name[nlen] = 0;
-    if (colon) seed = strtoull(colon + 1, NULL, 10);
+    const char* sc = NULL;                       /* "synthetic:<config>[:seed[:scorer]]", scorer = simple | weighted-dot | mlp */
+    if (colon) { char* end = NULL; seed = strtoull(colon + 1, &end, 10); if (end && *end == ':') sc = end + 1; }
     if (glc_named_config(name, &w->cfg) != 0) { fprintf(stderr, "Error: unknown synthetic config '%s'\n", name); return -1; }
+    if (sc) {
+        if (!strcmp(sc, "simple")) w->cfg.scorer = GLC_SCORER_DOT;
+        else if (!strcmp(sc, "weighted-dot")) w->cfg.scorer = GLC_SCORER_WEIGHTED_DOT;
+        else if (!strcmp(sc, "mlp")) w->cfg.scorer = GLC_SCORER_MLP;
+        else { fprintf(stderr, "Error: unknown scorer '%s' in '%s' (simple, weighted-dot, mlp)\n", sc, spec); return -1; }
+    }
     w->n_tensors = glc_num_tensors_cfg(&w->cfg);
     w->tensors = (const float**)calloc((size_t)w->n_tensors, sizeof(float*));
     if (!w->tensors) return -1;

@@ -16,7 +16,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from .config import GLiClassConfig, BACKBONE_DECODER
+from .config import GLiClassConfig, BACKBONE_DECODER, SCORER_WEIGHTED_DOT, SCORER_MLP, SCORER_MLP_HIDDEN
 from . import prng
 
 MAGIC = b"GLCW\x00\x01\x00\x00"
@@ -51,6 +51,21 @@ def tensor_specs(cfg: GLiClassConfig) -> List[Tuple[str, Tuple[int, ...], float,
                 (proj + ".linear_1.bias", (H,), 0.1, 0.0),
                 (proj + ".linear_2.weight", (H, H), lin(t2, H), 0.0),
                 (proj + ".linear_2.bias", (H,), 0.02, 0.0),
+            ]
+        # the scorer's own tensors (include/gliclass_hip.h; mirrors head_spec in host/glc_weights.c)
+        if cfg.scorer == SCORER_WEIGHTED_DOT:
+            out += [
+                ("scorer.proj_text.weight", (2 * H, H), lin(1.0, H), 0.0), ("scorer.proj_text.bias", (2 * H,), 0.05, 0.0),
+                ("scorer.proj_label.weight", (2 * H, H), lin(1.0, H), 0.0), ("scorer.proj_label.bias", (2 * H,), 0.05, 0.0),
+                ("scorer.out_mlp.0.weight", (4 * H, 3 * H), lin(1.0, 3 * H), 0.0), ("scorer.out_mlp.0.bias", (4 * H,), 0.05, 0.0),
+                ("scorer.out_mlp.3.weight", (1, 4 * H), lin(2.0, 4 * H), 0.0), ("scorer.out_mlp.3.bias", (1,), 0.1, 0.0),
+            ]
+        elif cfg.scorer == SCORER_MLP:
+            Mh = SCORER_MLP_HIDDEN
+            out += [
+                ("scorer.mlp.0.weight", (Mh, 2 * H), lin(1.0, 2 * H), 0.0), ("scorer.mlp.0.bias", (Mh,), 0.05, 0.0),
+                ("scorer.mlp.2.weight", (Mh // 2, Mh), lin(1.5, Mh), 0.0), ("scorer.mlp.2.bias", (Mh // 2,), 0.05, 0.0),
+                ("scorer.mlp.4.weight", (1, Mh // 2), lin(3.0, Mh // 2), 0.0), ("scorer.mlp.4.bias", (1,), 0.1, 0.0),
             ]
         return out
 

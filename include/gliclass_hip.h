@@ -30,7 +30,11 @@ extern "C" {
  * the scorer head are always fp32) */
 enum { GLC_F32 = 0, GLC_BF16 = 1, GLC_F16 = 2 };
 enum { GLC_POOL_FIRST = 0, GLC_POOL_AVG = 1, GLC_POOL_LAST = 2 /* last attended token (decoder backbones) */ };
-enum { GLC_SCORER_DOT = 0 };
+/* scorer of the GLiClass head (upstream `scorer_type`; SURVEY.md §8a row a12 — restated, parity unpinned): 'simple' = dot product of the
+ * projected text and class features; 'weighted-dot' = out_mlp([t1, c1, t2 * c2]) on (t1|t2) = proj_text(text), (c1|c2) = proj_label(class),
+ * out_mlp = Linear(3H,4H) -> ReLU -> Linear(4H,1); 'mlp' = Linear(2H,256) -> ReLU -> Linear(256,128) -> ReLU -> Linear(128,1) on [text, class] */
+enum { GLC_SCORER_DOT = 0, GLC_SCORER_WEIGHTED_DOT = 1, GLC_SCORER_MLP = 2 };
+#define GLC_SCORER_MLP_HIDDEN 256
 /* backbone family: DeBERTa-v2/v3 disentangled encoder, or a decoder-style stack with Qwen2 arithmetic (RMSNorm, RoPE,
  * grouped-query attention, SwiGLU; SURVEY.md §8a row a16, BASELINE.json configs[4]) */
 enum { GLC_BACKBONE_DEBERTA = 0, GLC_BACKBONE_DECODER = 1 };
@@ -50,11 +54,16 @@ typedef struct glc_model_config {
  *   3 encoder.rel_embeddings.weight [2*span,H]         4,5 encoder.LayerNorm.{weight,bias}
  *   6+16*l .. : layer l: q.w q.b k.w k.b v.w v.b  attn.out.w attn.out.b attn.LN.w attn.LN.b
  *                        inter.w inter.b  out.w out.b out.LN.w out.LN.b
- *   then text_projector.linear_1.{w,b} linear_2.{w,b}, classes_projector.linear_1.{w,b} linear_2.{w,b} */
+ *   then text_projector.linear_1.{w,b} linear_2.{w,b}, classes_projector.linear_1.{w,b} linear_2.{w,b}
+ *   then the scorer's tensors (none for 'simple'):
+ *     weighted-dot: scorer.proj_text.{weight [2H,H], bias [2H]}  scorer.proj_label.{weight [2H,H], bias}
+ *                   scorer.out_mlp.0.{weight [4H,3H], bias [4H]}  scorer.out_mlp.3.{weight [1,4H], bias [1]}
+ *     mlp:          scorer.mlp.0.{weight [256,2H], bias}  scorer.mlp.2.{weight [128,256], bias}  scorer.mlp.4.{weight [1,128], bias [1]} */
 #define GLC_TENSORS_FIXED 6
 #define GLC_TENSORS_PER_LAYER 16
 #define GLC_TENSORS_HEAD 8
 static inline int glc_num_tensors(int layers) { return GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * layers + GLC_TENSORS_HEAD; }
+static inline int glc_num_scorer_tensors(int scorer) { return scorer == GLC_SCORER_WEIGHTED_DOT ? 8 : scorer == GLC_SCORER_MLP ? 6 : 0; }
 /* Decoder backbone (names of HF Qwen2Model.state_dict()):
  *   0 embed_tokens.weight [vocab,H]
  *   1+12*l .. : layer l: input_layernorm.weight  q_proj.{w,b} [nq*d,H]  k_proj.{w,b} [nkv*d,H]  v_proj.{w,b}
@@ -63,7 +72,8 @@ static inline int glc_num_tensors(int layers) { return GLC_TENSORS_FIXED + GLC_T
  *   then norm.weight [H], then the same 8 head tensors */
 #define GLC_DEC_TENSORS_PER_LAYER 12
 static inline int glc_num_tensors_cfg(const glc_model_config* c) {
-    return c->backbone == GLC_BACKBONE_DECODER ? 2 + GLC_DEC_TENSORS_PER_LAYER * c->layers + GLC_TENSORS_HEAD : glc_num_tensors(c->layers);
+    return (c->backbone == GLC_BACKBONE_DECODER ? 2 + GLC_DEC_TENSORS_PER_LAYER * c->layers + GLC_TENSORS_HEAD : glc_num_tensors(c->layers)) +
+           glc_num_scorer_tensors(c->scorer);
 }
 
 typedef struct glc_engine glc_engine;

@@ -41,12 +41,14 @@ typedef struct {
     /* decoder backbone (glo_forward_decoder): key/value heads, causal flag, RoPE base; ln_eps = rms_norm_eps */
     int32_t backbone, kv_heads, causal;
     float rope_theta;
+    int32_t scorer;    /* 0 'simple' (dot), 1 'weighted-dot', 2 'mlp' (upstream gliclass scorers; restated, parity unpinned) */
 } glo_config;
 
 /* tensor order = gliclass/c_amd/weights.py::tensor_specs */
 enum { T_WORD = 0, T_ELN_W, T_ELN_B, T_REL, T_RLN_W, T_RLN_B, T_LAYER0 };
 enum { L_QW = 0, L_QB, L_KW, L_KB, L_VW, L_VB, L_OW, L_OB, L_LN1W, L_LN1B, L_IW, L_IB, L_DW, L_DB, L_LN2W, L_LN2B, L_N };
-enum { H_T1W = 0, H_T1B, H_T2W, H_T2B, H_C1W, H_C1B, H_C2W, H_C2B };
+enum { H_T1W = 0, H_T1B, H_T2W, H_T2B, H_C1W, H_C1B, H_C2W, H_C2B, H_SCORER };
+#define GLO_SCORER_MLP_HIDDEN 256
 
 /* ---- HF:57-69 make_log_bucket_position, float32 arithmetic exactly as torch does it ---- */
 static int glo_bucket(int rel, int bucket_size, int max_position) {
@@ -185,6 +187,54 @@ static void glo_head(const glo_config* cfg, const float* const* hw, const float*
             nn = sqrtf(nn) + 1e-8f;
             for (int i = 0; i < H; ++i) G2[(size_t)r * H + i] /= nn;
         }
+    const float* const* sw = hw + H_SCORER;
+    if (cfg->scorer == 1 && C > 0) {
+        /* ScorerWeightedDot (upstream gliclass scorers.py, restated): (t1|t2) = proj_text(text) [2H], (c1|c2) = proj_label(class) [2H];
+         * score = out_mlp([t1, c1, t2 * c2]), out_mlp = Linear(3H, 4H) -> (Dropout) -> ReLU -> Linear(4H, 1) */
+        float* T = (float*)malloc((size_t)B * 2 * H * sizeof(float));
+        float* L = (float*)malloc((size_t)B * C * 2 * H * sizeof(float));
+        float* cat = (float*)malloc((size_t)B * C * 3 * H * sizeof(float));
+        float* hid = (float*)malloc((size_t)B * C * 4 * H * sizeof(float));
+        linear(G2, B, H, sw[0], sw[1], 2 * H, T);
+        linear(G2 + (size_t)B * H, B * C, H, sw[2], sw[3], 2 * H, L);
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < C; ++j) {
+                const float* t = T + (size_t)b * 2 * H;
+                const float* l = L + ((size_t)b * C + j) * 2 * H;
+                float* o = cat + ((size_t)b * C + j) * 3 * H;
+                for (int i = 0; i < H; ++i) { o[i] = t[i]; o[H + i] = l[i]; o[2 * H + i] = t[H + i] * l[H + i]; }
+            }
+        linear(cat, B * C, 3 * H, sw[4], sw[5], 4 * H, hid);
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < C; ++j) {
+                const float* hrow = hid + ((size_t)b * C + j) * 4 * H;
+                float a = 0;
+                for (int i = 0; i < 4 * H; ++i) a += (hrow[i] > 0.f ? hrow[i] : 0.f) * sw[6][i];
+                logits[(size_t)b * c_alloc + j] = a + sw[7][0];
+            }
+        free(T); free(L); free(cat); free(hid);
+    } else if (cfg->scorer == 2 && C > 0) {
+        /* MLPScorer (restated): Linear(2H, 256) -> ReLU -> Linear(256, 128) -> ReLU -> Linear(128, 1) on [text, class] */
+        const int Mh = GLO_SCORER_MLP_HIDDEN;
+        float* cat = (float*)malloc((size_t)B * C * 2 * H * sizeof(float));
+        float* h1 = (float*)malloc((size_t)B * C * Mh * sizeof(float));
+        float* h2 = (float*)malloc((size_t)B * C * (Mh / 2) * sizeof(float));
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < C; ++j) {
+                float* o = cat + ((size_t)b * C + j) * 2 * H;
+                memcpy(o, G2 + (size_t)b * H, (size_t)H * sizeof(float));
+                memcpy(o + H, G2 + ((size_t)B + (size_t)b * C + j) * H, (size_t)H * sizeof(float));
+            }
+        linear(cat, B * C, 2 * H, sw[0], sw[1], Mh, h1);
+        for (size_t i = 0; i < (size_t)B * C * Mh; ++i) h1[i] = h1[i] > 0.f ? h1[i] : 0.f;
+        linear(h1, B * C, Mh, sw[2], sw[3], Mh / 2, h2);
+        for (int r = 0; r < B * C; ++r) {
+            float a = 0;
+            for (int i = 0; i < Mh / 2; ++i) { const float v = h2[(size_t)r * (Mh / 2) + i]; a += (v > 0.f ? v : 0.f) * sw[4][i]; }
+            logits[(size_t)(r / C) * c_alloc + (r % C)] = a + sw[5][0];
+        }
+        free(cat); free(h1); free(h2);
+    } else
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < C; ++j) {
             float a = 0;

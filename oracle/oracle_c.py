@@ -20,7 +20,7 @@ class GloConfig(C.Structure):
                                          "pos_buckets", "max_rel_pos", "pad_id", "class_token_index",
                                          "embed_class_token", "pooling", "normalize_features")] + \
                [("ln_eps", C.c_float), ("logit_scale", C.c_float)] + \
-               [(n, C.c_int32) for n in ("backbone", "kv_heads", "causal")] + [("rope_theta", C.c_float)]
+               [(n, C.c_int32) for n in ("backbone", "kv_heads", "causal")] + [("rope_theta", C.c_float), ("scorer", C.c_int32)]
 
 
 def build(force=False):
@@ -64,7 +64,7 @@ def _cfg(cfg: GLiClassConfig) -> GloConfig:
     return GloConfig(cfg.vocab, cfg.hidden, cfg.layers, cfg.heads, cfg.head_dim, cfg.inter, cfg.pos_buckets,
                      cfg.max_rel_pos, cfg.pad_id, cfg.class_token_index, cfg.embed_class_token, cfg.pooling,
                      cfg.normalize_features, cfg.ln_eps, cfg.logit_scale, cfg.backbone, cfg.kv_heads, cfg.causal,
-                     cfg.rope_theta)
+                     cfg.rope_theta, cfg.scorer)
 
 
 def delta_table(S, bucket_size=256, max_position=512):

@@ -402,6 +402,35 @@ def test_pooling_switches(pooling, weights_for):
         assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], dtype
 
 
+@pytest.mark.parametrize("scorer", ["weighted-dot", "mlp"])
+def test_scorer_switches(scorer, weights_for):
+    """scorer_type = 'weighted-dot' / 'mlp' ("must be config-switchable"; module structure restated from
+    the upstream package, include/gliclass_hip.h — parity with upstream unpinned; the oracle's versions are pinned to torch.nn modules in
+    tests/test_oracle.py).  Engine vs oracle in fp32 and f16, ragged rows with different label counts (padded class slots score the
+    projected zero row, as in the oracle); the encoder through Python-side tensors, the decoder backbone and the pruned path through
+    the C weight source's "synthetic:<config>:<seed>:<scorer>" spec (same PRNG, so the same tensors)."""
+    import dataclasses
+    import oracle_c
+    from gliclass.c_amd import synth, weights
+    from gliclass.c_amd.config import CONFIGS, SCORER_NAMES
+    from gliclass.c_amd.engine import Engine
+    for cname, shape in (("tiny", (4, 150, 3, [3, 1, 0, 2])), ("dec-tiny", (3, 96, 2, [2, 1, 2])), ("mini", (5, 200, 4, [4, 4, 2, 0, 3]))):
+        cfg = dataclasses.replace(CONFIGS[cname], scorer=SCORER_NAMES[scorer])
+        w = weights.make_weights(cfg, 42)
+        B, S, Cn, per_row = shape
+        ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=17, ragged=True, labels_per_row=per_row)
+        ref = oracle_c.forward(cfg, w, ids, mask)
+        assert np.abs(ref).max() > 0.05
+        for dtype in ("f32", "f16"):
+            eng = Engine(cfg, w, dtype=dtype) if cname == "tiny" else Engine.from_spec(cfg, f"synthetic:{cname}:42:{scorer}", dtype=dtype)
+            try:
+                got = eng.forward(ids, mask)
+            finally:
+                eng.close()
+            assert got.shape == ref.shape
+            assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (cname, dtype)
+
+
 def test_length_bucketing_decoder_backbone(engines, weights_for):
     """The same bucketing on the decoder backbone (last-token pooling reads each group's own lengths)."""
     from gliclass.c_amd import synth

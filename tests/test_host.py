@@ -100,8 +100,11 @@ def test_weight_sources_synthetic_and_blob(libs, tmp_path):
     _lib, hip, model = libs
     from gliclass.c_amd import weights
     from gliclass.c_amd.config import CONFIGS
-    for cname in ("tiny", "dec-tiny"):                  # both backbone families; the blob header (v2) carries the family
-        cfg = CONFIGS[cname]
+    import dataclasses
+    from gliclass.c_amd.config import SCORER_NAMES
+    for cname, scorer in (("tiny", None), ("dec-tiny", None), ("tiny", "weighted-dot"), ("dec-tiny", "mlp")):
+        # both backbone families (the blob header, v2, carries the family) and the scorers that bring tensors of their own
+        cfg = CONFIGS[cname] if scorer is None else dataclasses.replace(CONFIGS[cname], scorer=SCORER_NAMES[scorer])
         ref = weights.make_weights(cfg, 7)
         names = [s[0] for s in weights.tensor_specs(cfg)]
         path = str(tmp_path / (cname + ".glcw"))
@@ -109,12 +112,13 @@ def test_weight_sources_synthetic_and_blob(libs, tmp_path):
         cfg2, back = weights.read_blob(path)
         assert cfg2.hidden == cfg.hidden and cfg2.backbone == cfg.backbone and cfg2.kv_heads == cfg.kv_heads
         assert cfg2.causal == cfg.causal and abs(cfg2.rope_theta - cfg.rope_theta) < 1.0 and cfg2.pooling == cfg.pooling
-        assert all(np.array_equal(back[n], ref[n]) for n in names)
-        for src in (f"synthetic:{cname}:7".encode(), path.encode()):
+        assert all(np.array_equal(back[n], ref[n]) for n in names) and cfg2.scorer == cfg.scorer
+        for src in ((f"synthetic:{cname}:7" + (":" + scorer if scorer else "")).encode(), path.encode()):
             W = _lib.Weights()
             assert model.glc_weights_load(src, C.byref(W)) == 0
             assert W.n_tensors == len(names) and W.cfg.hidden == cfg.hidden and W.cfg.class_token_index == cfg.class_token_index
             assert W.cfg.backbone == cfg.backbone and W.cfg.kv_heads == cfg.kv_heads and W.cfg.head_dim == cfg.head_dim
+            assert W.cfg.scorer == cfg.scorer
             for i, n in enumerate(names):
                 got = np.ctypeslib.as_array(W.tensors[i], shape=(ref[n].size,))
                 assert np.array_equal(got, ref[n].ravel()), n
@@ -122,6 +126,7 @@ def test_weight_sources_synthetic_and_blob(libs, tmp_path):
     W = _lib.Weights()
     assert model.glc_weights_load(b"/nonexistent.glcw", C.byref(W)) != 0
     assert model.glc_weights_load(b"synthetic:nope", C.byref(W)) != 0
+    assert model.glc_weights_load(b"synthetic:tiny:7:hopfield", C.byref(W)) != 0       # a scorer that is not implemented is refused by name
     bad = tmp_path / "bad.glcw"
     bad.write_bytes(b"\0" * 512)
     assert model.glc_weights_load(str(bad).encode(), C.byref(W)) != 0
@@ -325,7 +330,8 @@ def _hf_config_json(cfg, **over):
                "num_key_value_heads": cfg.kv_heads, "intermediate_size": cfg.inter, "vocab_size": cfg.vocab - 2, "rms_norm_eps": cfg.ln_eps,
                "rope_theta": cfg.rope_theta}
     top = {"model_type": "GLiClass", "architecture_type": "uni-encoder", "encoder_config": enc, "class_token_index": cfg.class_token_index,
-           "text_token_index": cfg.text_token_index, "pooling_strategy": {0: "first", 1: "avg", 2: "last"}[cfg.pooling], "scorer_type": "simple",
+           "text_token_index": cfg.text_token_index, "pooling_strategy": {0: "first", 1: "avg", 2: "last"}[cfg.pooling],
+           "scorer_type": {0: "simple", 1: "weighted-dot", 2: "mlp"}[cfg.scorer],
            "embed_class_token": True, "normalize_features": False, "use_lstm": False, "vocab_size": cfg.vocab}
     top.update(over)
     return top
@@ -340,14 +346,17 @@ def test_native_hf_checkpoint_import(libs, tmp_path):
     _lib, hip, model = libs
     from gliclass.c_amd import weights
     from gliclass.c_amd.config import CONFIGS
-    for cname, prefix in (("tiny", "encoder_model.model."), ("dec-tiny", "decoder_model.model.")):
-        cfg = CONFIGS[cname]
+    import dataclasses
+    from gliclass.c_amd.config import SCORER_NAMES
+    for cname, prefix, scorer in (("tiny", "encoder_model.model.", "simple"), ("dec-tiny", "decoder_model.model.", "simple"),
+                                  ("tiny", "encoder_model.model.", "weighted-dot"), ("dec-tiny", "decoder_model.model.", "mlp")):
+        cfg = dataclasses.replace(CONFIGS[cname], scorer=SCORER_NAMES[scorer])
         ref = weights.make_weights(cfg, 11)
         names = [s[0] for s in weights.tensor_specs(cfg)]
-        for dt in (torch.float32, torch.float16, torch.bfloat16):
-            d = tmp_path / f"{cname}_{str(dt).split('.')[-1]}"
+        for dt in (torch.float32, torch.float16, torch.bfloat16) if scorer == "simple" else (torch.float32,):
+            d = tmp_path / f"{cname}_{scorer}_{str(dt).split('.')[-1]}"
             d.mkdir()
-            sd = {(prefix if "projector" not in n else "") + n: torch.from_numpy(ref[n]).to(dt) for n in names}
+            sd = {(prefix if "projector" not in n and not n.startswith("scorer.") else "") + n: torch.from_numpy(ref[n]).to(dt) for n in names}
             sd["some.unrelated.buffer"] = torch.zeros(3, dtype=torch.int64)
             st.save_file(sd, str(d / "model.safetensors"), metadata={"format": "pt"})
             (d / "config.json").write_text(json.dumps(_hf_config_json(cfg)))
@@ -368,8 +377,8 @@ def test_native_hf_checkpoint_import(libs, tmp_path):
                 model.glc_weights_free(C.byref(W))
     # refusals (message on stderr, -1)
     cfg = CONFIGS["tiny"]
-    d = tmp_path / "tiny_float32"
-    for over in ({"scorer_type": "mlp"}, {"architecture_type": "bi-encoder"}, {"use_lstm": True}, {"pooling_strategy": "max"}):
+    d = tmp_path / "tiny_simple_float32"
+    for over in ({"scorer_type": "hopfield"}, {"scorer_type": "mlp"}, {"architecture_type": "bi-encoder"}, {"use_lstm": True}, {"pooling_strategy": "max"}):
         (d / "config.json").write_text(json.dumps(_hf_config_json(cfg, **over)))
         W = _lib.Weights()
         assert model.glc_weights_load(str(d).encode(), C.byref(W)) != 0, over

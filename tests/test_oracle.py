@@ -59,3 +59,42 @@ def test_sigmoid_matches_reference_formula():
     lib = oracle_c.lib()
     for x in (-20.0, -1.5, 0.0, 0.3, 7.0):
         assert abs(lib.glo_sigmoid(x) - 1.0 / (1.0 + np.exp(-x))) < 1e-7
+
+
+@pytest.mark.parametrize("scorer", ["weighted-dot", "mlp"])
+def test_oracle_scorer_variants_vs_torch_modules(scorer):
+    """The head's other scorers ('must be config-switchable'): the C oracle against the same modules written
+    with torch.nn, on the oracle's own final hidden states.  The module structure is the upstream `gliclass` package's as restated in
+    include/gliclass_hip.h (not on disk here: parity with upstream stays unpinned); this pins the oracle's arithmetic to torch's."""
+    import dataclasses
+    import torch
+    from gliclass.c_amd.config import CONFIGS, SCORER_NAMES
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.weights import make_weights
+    cfg = dataclasses.replace(CONFIGS["tiny"], scorer=SCORER_NAMES[scorer])
+    w = make_weights(cfg, 7)
+    B, S, C = 3, 48, 3
+    ids, mask, _ = synth.make_inputs(cfg, B, S, C, seed=5, ragged=True)
+    logits, hidden = oracle_c.forward(cfg, w, ids, mask, want_hidden=True)
+    assert logits.shape == (B, C)
+    H = cfg.hidden
+    X = torch.tensor(hidden[-1])
+    T = lambda n: torch.tensor(w[n])
+    lin = lambda x, p: torch.nn.functional.linear(x, T(p + ".weight"), T(p + ".bias"))
+    proj = lambda x, p: lin(torch.nn.functional.gelu(lin(x, p + ".linear_1")), p + ".linear_2")
+    text = proj(X[:, 0, :], "text_projector")                                       # pooling 'first'
+    pos = np.stack([np.nonzero(ids[b] == cfg.class_token_index)[0][:C] for b in range(B)])
+    cls = proj(torch.stack([X[b, pos[b], :] for b in range(B)]), "classes_projector")     # [B, C, H]
+    if scorer == "weighted-dot":
+        t = lin(text, "scorer.proj_text").view(B, 1, 1, 2, H)
+        l = lin(cls, "scorer.proj_label").view(B, 1, C, 2, H)
+        t = t.expand(-1, -1, C, -1, -1).permute(3, 0, 1, 2, 4)
+        l = l.expand(-1, 1, -1, -1, -1).permute(3, 0, 1, 2, 4)
+        cat = torch.cat([t[0], l[0], t[1] * l[1]], dim=-1)
+        want = lin(torch.relu(lin(cat, "scorer.out_mlp.0")), "scorer.out_mlp.3").view(B, C)
+    else:
+        comb = torch.cat([text.unsqueeze(1).expand(-1, C, -1), cls], dim=-1)
+        want = lin(torch.relu(lin(torch.relu(lin(comb, "scorer.mlp.0")), "scorer.mlp.2")), "scorer.mlp.4").squeeze(-1)
+    want = want.numpy()
+    assert np.abs(want).max() > 0.05 and np.abs(want).max() < 30, "synthetic scorer weights should give logits in the sigmoid's range"
+    np.testing.assert_allclose(logits, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))

@@ -107,7 +107,7 @@ struct glc_engine {
     float* scorer_ws = nullptr;          // its row buffers
     int P = 0;
     // workspace
-    int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0, capSel = 0;
+    int capM = 0, capB = 0, capIds = 0, capC = 0, capHeadRows = 0, capSel = 0, capGU = 0;
     void *Xs = nullptr, *Qs = nullptr, *CTXs = nullptr, *T1s = nullptr, *H1s = nullptr, *FFs = nullptr;   // compact rows of the pruned last layer
     int *sel_b = nullptr, *sel_q = nullptr;
     unsigned char* tile_flag = nullptr; size_t capFlag = 0;
@@ -207,7 +207,9 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
             dfree(e, e->Kh); e->Kh = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Kh) return false;
             dfree(e, e->Vt); e->Vt = dmalloc(e, (size_t)Mpad * nkvd * es); if (!e->Vt) return false;
         }
-        if (!e->fused_swiglu || e->dtype == GLC_F32) { dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * c.inter * es); if (!e->GU) return false; }
+        // [gate | up] rows: read only by the launches without the SwiGLU epilogue (unfused builds, the fp32 mode's small forwards) — allocated
+        // by the forward that takes such a launch (need_gu), not for every capacity step (2.3 GB at c5 that the group-split pipeline never touches)
+        dfree(e, e->GU); e->GU = nullptr; e->capGU = 0;
         dfree(e, e->FF); e->FF = dmalloc(e, (size_t)Mpad * c.inter * es); if (!e->FF) return false;
         if (e->dtype == GLC_F32) {             // RMSNorm statistics of the two residual-stream buffers + the producers' partials
             dfree(e, e->statsA); e->statsA = (float2*)dmalloc(e, (size_t)Mpad * sizeof(float2)); if (!e->statsA) return false;
@@ -481,6 +483,12 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         { Prof p(e, PC_LN); KCHK(rnf ? glc_launch_ln_stats(st, e->ln_part, H / 64, sX, M, H, c.ln_eps, 1)
                                  : gs ? glc_launch_rmsnorm_gs(st, (const float*)X, e->H1, w.ln2, c.ln_eps, M, H)
                                       : glc_launch_rmsnorm(st, dt, X, e->H1, w.ln2, c.ln_eps, M, H), false); }                        // Q2:295
+        const bool need_gu = !(e->fused_swiglu && (gs || dt != GLC_F32));
+        if (need_gu && e->capGU < Mpad) {
+            dfree(e, e->GU); e->GU = dmalloc(e, (size_t)Mpad * 2 * I * es);
+            if (!e->GU) return false;
+            e->capGU = Mpad;
+        }
         GemmArgs f1;
         f1.A = e->H1; f1.W = w.Wgu; f1.bias = nullptr; f1.C = e->GU; f1.Mpad = Mpad; f1.N = 2 * I; f1.K = H;
         if (rnf) { f1.A = X; f1.W = w.Wguf; f1.a_stats = sX; }

@@ -879,6 +879,60 @@ static const bpe_merge* merge_find(const glc_tokenizer* tk, int32_t l, int32_t r
     return NULL;
 }
 
+/* Long pre-tokens (a run of thousands of letters without whitespace): the rescan below is O(n^2) hash lookups; this is the Rust
+ * implementation's own method — symbols as a linked list, candidate pairs in a min-heap ordered by (rank, position), stale entries
+ * (a side already merged away, or merged into something else) skipped when popped — O(n log n), same merge order. */
+#define BPE_HEAP_MIN 48
+typedef struct { int32_t rank; uint32_t pos; int32_t l, r, merged; } bpe_cand;
+static int cand_less(const bpe_cand* a, const bpe_cand* b) { return a->rank != b->rank ? a->rank < b->rank : a->pos < b->pos; }
+static void heap_push(bpe_cand* h, size_t* n, bpe_cand c) {
+    size_t i = (*n)++;
+    while (i) { const size_t p = (i - 1) / 2; if (!cand_less(&c, &h[p])) break; h[i] = h[p]; i = p; }
+    h[i] = c;
+}
+static bpe_cand heap_pop(bpe_cand* h, size_t* n) {
+    const bpe_cand top = h[0], last = h[--(*n)];
+    size_t i = 0;
+    for (;;) {
+        size_t k = 2 * i + 1;
+        if (k >= *n) break;
+        if (k + 1 < *n && cand_less(&h[k + 1], &h[k])) ++k;
+        if (!cand_less(&h[k], &last)) break;
+        h[i] = h[k]; i = k;
+    }
+    if (*n) h[i] = last;
+    return top;
+}
+static int bpe_merge_heap(const glc_tokenizer* tk, int32_t* sym, size_t* pns) {
+    const size_t ns = *pns;
+    int32_t* prev = (int32_t*)malloc(ns * sizeof(int32_t));
+    int32_t* next = (int32_t*)malloc(ns * sizeof(int32_t));
+    bpe_cand* heap = (bpe_cand*)malloc(3 * ns * sizeof(bpe_cand));       /* n - 1 initial pairs + at most two per merge */
+    if (!prev || !next || !heap) { free(prev); free(next); free(heap); return 0; }
+    size_t hn = 0;
+    for (size_t k = 0; k < ns; ++k) { prev[k] = (int32_t)k - 1; next[k] = k + 1 < ns ? (int32_t)k + 1 : -1; }
+    for (size_t k = 0; k + 1 < ns; ++k) {
+        const bpe_merge* m = merge_find(tk, sym[k], sym[k + 1]);
+        if (m) heap_push(heap, &hn, (bpe_cand){m->rank, (uint32_t)k, sym[k], sym[k + 1], m->merged});
+    }
+    while (hn) {
+        const bpe_cand c = heap_pop(heap, &hn);
+        const int32_t i = (int32_t)c.pos, j = sym[i] >= 0 ? next[i] : -1;
+        if (j < 0 || sym[i] != c.l || sym[j] != c.r) continue;            /* stale: a side was merged since this pair was queued */
+        sym[i] = c.merged;
+        sym[j] = -1;                                                      /* dead */
+        next[i] = next[j];
+        if (next[j] >= 0) prev[next[j]] = i;
+        if (prev[i] >= 0) { const bpe_merge* m = merge_find(tk, sym[prev[i]], sym[i]); if (m) heap_push(heap, &hn, (bpe_cand){m->rank, (uint32_t)prev[i], sym[prev[i]], sym[i], m->merged}); }
+        if (next[i] >= 0) { const bpe_merge* m = merge_find(tk, sym[i], sym[next[i]]); if (m) heap_push(heap, &hn, (bpe_cand){m->rank, (uint32_t)i, sym[i], sym[next[i]], m->merged}); }
+    }
+    size_t o = 0;
+    for (int32_t k = 0; k >= 0; k = next[k]) sym[o++] = sym[k];          /* symbol 0 never dies (a merge keeps its left slot) */
+    *pns = o;
+    free(prev); free(next); free(heap);
+    return 1;
+}
+
 /* One pre-token (already mapped to its printable stand-ins, UTF-8): symbols = characters, then merge the lowest-rank adjacent
  * pair (leftmost among equals) until none is left — the order the Rust implementation's heap pops them in. */
 static void bpe_word(const glc_tokenizer* tk, const char* w, size_t n, scratch* sc, ivec* out) {
@@ -891,7 +945,8 @@ static void bpe_word(const glc_tokenizer* tk, const char* w, size_t n, scratch* 
         if (id >= 0) sym[ns++] = id; else if (tk->unk_id >= 0) sym[ns++] = tk->unk_id;        /* no unk token: the character is dropped */
         i += l;
     }
-    while (ns > 1) {
+    if (ns > BPE_HEAP_MIN && bpe_merge_heap(tk, sym, &ns)) { for (size_t k = 0; k < ns; ++k) iv_push(out, sym[k]); return; }
+    while (ns > 1) {                                                      /* short words (and the heap's allocation-failure fallback): rescan */
         int32_t best = INT32_MAX; size_t at = 0; int32_t merged = -1;
         for (size_t k = 0; k + 1 < ns; ++k) {
             const bpe_merge* m = merge_find(tk, sym[k], sym[k + 1]);

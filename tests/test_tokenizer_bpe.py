@@ -98,6 +98,10 @@ def test_live_against_rust_tokenizers(tk_json):
     variants["ignore-merges"] = im
     rnd = random.Random(20261003)
     texts = [_rand_text(rnd) for _ in range(400)] + ["<<LABEL>>a b<<LABEL>>c<<SEP>> " + _rand_text(rnd) for _ in range(40)]
+    # long pre-tokens (no whitespace): the heap merge of bpe_word (pre-tokens beyond 48 symbols) must pop pairs in the Rust library's order
+    letters = "etaoinshrdlucmfwypvbgkqjxzETAOIN"
+    texts += ["".join(rnd.choice(letters) for _ in range(n)) for n in (49, 50, 97, 300, 2000)]
+    texts += [" " + "".join(rnd.choice("theandingersto") for _ in range(700)) + " end", "a" * 5000, "ab" * 1500 + "c", "é" * 400 + "x" * 64]
     for name, js in variants.items():
         s = json.dumps(js)
         ref = tokenizers.Tokenizer.from_str(s)

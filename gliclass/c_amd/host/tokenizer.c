@@ -725,7 +725,12 @@ static const glc_decomp* nfc_decomp(uint32_t c) {
 }
 enum { H_SB = 0xAC00, H_LB = 0x1100, H_VB = 0x1161, H_TB = 0x11A7, H_LC = 19, H_VC = 21, H_TC = 28, H_NC = 21 * 28, H_SC = 19 * 21 * 28 };
 static void nfc_push_decomposed(uint32_t c, uint32_t** buf, size_t* n, size_t* cap) {
-    if (*n + 4 > *cap) { *cap = *cap ? *cap * 2 : 64; *buf = (uint32_t*)realloc(*buf, *cap * sizeof(uint32_t)); }
+    if (*n + 4 > *cap) {
+        const size_t nc = *cap ? *cap * 2 : 64;
+        uint32_t* nb = (uint32_t*)realloc(*buf, nc * sizeof(uint32_t));
+        if (!nb) return;                                                  /* out of memory: the character is dropped, the buffer stays valid */
+        *buf = nb; *cap = nc;
+    }
     if (c >= H_SB && c < H_SB + H_SC) {
         const uint32_t si = c - H_SB;
         (*buf)[(*n)++] = H_LB + si / H_NC; (*buf)[(*n)++] = H_VB + (si % H_NC) / H_TC;

@@ -129,6 +129,34 @@ def test_c3_default_mode_other_weight_seeds(seed, c_generated_weights):
         eng.close()
 
 
+@pytest.mark.parametrize("scorer", ["weighted-dot", "mlp"])
+def test_c3_shape_with_other_scorers(scorer, c_generated_weights):
+    """The headline shape with the head's other scorers (row a12): the whole default pipeline — MX projections and attention, the pruned
+    last layer, the compacted head rows — feeding `weighted-dot` / `mlp`; two rows against the oracle, all 512 probabilities MX against split."""
+    import dataclasses
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS, SCORER_NAMES
+    from gliclass.c_amd.engine import Engine
+    cfg = dataclasses.replace(CONFIGS["base"], scorer=SCORER_NAMES[scorer])
+    spec = f"synthetic:base:42:{scorer}"
+    w = c_generated_weights(spec, cfg)
+    B, S, Cn = 64, 1024, 8
+    ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=1234)
+    eng = Engine.from_spec(cfg, spec, dtype="f32")
+    try:
+        eng.set_length_buckets(1)
+        got = eng.forward(ids, mask)
+        assert got.shape == (B, Cn) and np.isfinite(got).all() and eng.last_mx()
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [5, 58], TOL_MX)
+        eng.set_mx(False)
+        exact = eng.forward(ids, mask)
+        d = float(np.abs(sig(got) - sig(exact)).max())
+        print(f"c3 {scorer}: rows 5, 58 vs oracle {err:.2e}; MX vs split over 512 probabilities {d:.2e}; logit range [{got.min():.2f}, {got.max():.2f}]")
+        assert d <= TOL_MX
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_c4_large_shard_b32_s1024(dtype, c_generated_weights):
     from gliclass.c_amd import synth

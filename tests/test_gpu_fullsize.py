@@ -43,6 +43,29 @@ def _check_rows_vs_oracle(cfg, w, ids, mask, got, rows, tol):
     return err
 
 
+def test_c1_small_b1_s128(c_generated_weights):
+    """BASELINE.json configs[0] at its exact shape: gliclass-small, batch 1, seq 128, 4 labels (the reference's own CPU-runnable case) — the
+    one row vs the oracle in the default mode and in the 16-bit modes at their envelopes; a small forward (split-f16 arithmetic, 128-tile GEMMs)."""
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    cfg = CONFIGS["small"]
+    spec = "synthetic:small:42"
+    w = c_generated_weights(spec, cfg)
+    ids, mask, _ = synth.make_inputs(cfg, 1, 128, 4, seed=1234)
+    for dtype in ("f32", "f16"):
+        eng = Engine.from_spec(cfg, spec, dtype=dtype)
+        try:
+            got = eng.forward(ids, mask)
+            assert got.shape == (1, 4) and np.isfinite(got).all()
+            if dtype == "f32":
+                assert not eng.last_mx()
+            err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [0], TOL_DEFAULT_MODE if dtype == "f32" else _tol(dtype))
+            print(f"c1 {dtype}: max |prob - oracle| = {err:.2e} (bar {BAR})")
+        finally:
+            eng.close()
+
+
 def test_c2_small_b8_s512(c_generated_weights):
     """BASELINE.json configs[1] at its exact shape: gliclass-small, batch 8, seq 512, fp32 (the default mode) — all 8 rows vs the oracle."""
     from gliclass.c_amd import synth

@@ -16,6 +16,15 @@
 // to ~4 bits: ~2^-15 relative per product (split units: 2^-21; single f16: 2^-11).  The probabilities are split on the fly:
 // P = f16(p) for the f16 MFMAs, p_hi8 = e4m3(p), p_lo8 = e4m3((p - f16(p)) 2^SHIFT) for the scaled one (p <= 2^8 with the deferred
 // rescale: inside the e4m3 range).  Everything else — scores, softmax, the position gathers, the fp32 accumulators — is unchanged.
+//
+// Two workgroup shapes of the same code (template parameter NW):
+//   NW = 8  one workgroup per CU: 8 query tiles, ring of three [K | V^T] slots (156 KB of LDS), key tile t + 2 requested after barrier Y
+//           of tile t, two barriers per band tile.
+//   NW = 4  TWO workgroups per CU (default since the end of round 3): 4 query tiles, 80 KB of LDS each — one K slot and two V^T slots:
+//           K(t + 1) and V^T(t + 1) are requested once every wave holds its K(t) fragments (after barrier X) and published by a third
+//           barrier Z at the start of tile t + 1.  Twice the K / V^T bytes per query and a quarter instead of an eighth of the tiles
+//           carrying the unowned block, but the two workgroups of a CU are independent: their phases do not coincide, and a barrier
+//           holds 4 waves instead of 8.  Same box, c3: 1.22 -> 1.15 ms per launch, forward 37.84 -> 37.19 / 37.47 ms.
 #include <stdio.h>
 #include <stdlib.h>
 #include "glc_common.h"
@@ -26,10 +35,11 @@ namespace {
 
 constexpr float RESCALE_THR = 8.0f;   // log2 units (as attention.hip)
 constexpr int LROW = 68;              // floats per c2p ring row (2 blocks of 32 + 4 pad)
-constexpr int NW = 8;                 // waves = query tiles per workgroup
-constexpr int LROWP = 32 * (NW + 1) + 4;   // floats per p2c image row
 constexpr int TILEB = GLC_MXT_BYTES;  // one K tile, or one V^T tile
-constexpr int SLOTB = 2 * TILEB;      // ring slot: K tile | V^T tile
+constexpr int SLOTB = 2 * TILEB;      // NW = 8 ring slot: K tile | V^T tile
+template <int NW> constexpr size_t mx_lds_bytes() {        // c2p rings + p2c image + [NW = 8: 3 x (K | V^T); NW = 4: K | V^T even | V^T odd]
+    return ((size_t)NW * 32 * LROW + 32 * (32 * (NW + 1) + 4)) * sizeof(float) + (NW == 8 ? 3 * SLOTB : 3 * TILEB);
+}
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
@@ -63,8 +73,10 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 // 2 = without the fp8 conversion of the probabilities.
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them; the stamps
 // pin the instruction order at each boundary, so the stamped build is slower than the one it describes).
-template <int ABL = 0, bool DIAG = false>
+template <int NW, int ABL = 0, bool DIAG = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
+    static_assert(NW == 8 || NW == 4, "workgroup shapes: 8 waves x 1 per CU, 4 waves x 2 per CU");
+    constexpr int LROWP = 32 * (NW + 1) + 4;            // floats per p2c image row
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int Sp = a.Sp;
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     };
     // ring images: f16 units as they are (16 B per lane), MX steps re-arranged by the DMA into [64 lanes x first | 64 lanes x second]
     auto k_tile = [&](int t, MxFrag& f) __attribute__((always_inline)) {
-        const unsigned char* tile = kv_ring + (size_t)(t % 3) * SLOTB;
+        const unsigned char* tile = NW == 8 ? kv_ring + (size_t)(t % 3) * SLOTB : kv_ring;      // (NW = 4: the one K slot)
 #pragma unroll
         for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(tile + s * 1024 + lane * 16);
 #pragma unroll
@@ -165,22 +177,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     // f16 units, 4-7 the two MX steps; V^T tile (pieces 8-15): per 4-KiB sub-tile [2 f16 units | one MX step].  An MX step's two pieces
     // are its lanes' first / second 16 bytes (per-lane source address: the DMA gathers).
     const unsigned off16 = lane * 16, off32 = lane * 32;
-    const bool mx_piece = wave < 4 ? wave >= 2 : (wave & 1);          // wave-uniform: this wave's pieces belong to an MX step
-    const int piece_src = (wave & 3) * 2048;                          // byte offset of this wave's piece pair inside its tile (memory and ring image alike)
+    const int piece_src = (wave & 3) * 2048;                          // byte offset of this wave's piece pair inside its tile (memory and LDS image alike)
     auto uniform_ptr = [](const unsigned char* q) -> const unsigned char* {
         const unsigned long long v = reinterpret_cast<unsigned long long>(q);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
     };
+    auto dma_pair = [&](const unsigned char* src, unsigned char* dst, const bool mx_piece) __attribute__((always_inline)) {
+        if (mx_piece) { glds16_sv(uniform_ptr(src), off32, dst); glds16_sv(uniform_ptr(src + 16), off32, dst + 1024); }
+        else { glds16_sv(uniform_ptr(src), off16, dst); glds16_sv(uniform_ptr(src + 1024), off16, dst + 1024); }
+    };
+    // NW = 8: key tile t into ring slot t % 3, waves 0-3 the K tile's four piece pairs, waves 4-7 the V^T tile's.
+    // NW = 4: K into the one K slot, V^T into V slot t & 1; wave w moves the pairs the 8-wave form gives to its waves w and 4 + w.
     auto dma_tile = [&](int t) {
-        unsigned char* dst = kv_ring + (size_t)(t % 3) * SLOTB + (wave < 4 ? 0 : TILEB) + piece_src;
-        const unsigned char* src = (wave < 4 ? Kg : Vg) + (size_t)t * TILEB + piece_src;
-        if (mx_piece) {
-            glds16_sv(uniform_ptr(src), off32, dst);
-            glds16_sv(uniform_ptr(src + 16), off32, dst + 1024);
+        if constexpr (NW == 8) {
+            dma_pair((wave < 4 ? Kg : Vg) + (size_t)t * TILEB + piece_src, kv_ring + (size_t)(t % 3) * SLOTB + (wave < 4 ? 0 : TILEB) + piece_src,
+                     wave < 4 ? wave >= 2 : (wave & 1));
         } else {
-            glds16_sv(uniform_ptr(src), off16, dst);
-            glds16_sv(uniform_ptr(src + 1024), off16, dst + 1024);
+            dma_pair(Kg + (size_t)t * TILEB + piece_src, kv_ring + piece_src, wave >= 2);
+            dma_pair(Vg + (size_t)t * TILEB + piece_src, kv_ring + TILEB + (size_t)(t & 1) * TILEB + piece_src, (wave & 1) != 0);
         }
     };
 
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) qf.x[m] = cat8(*reinterpret_cast<const i32x4*>(Qg + 4096 + m * 2048 + lane * 32), *reinterpret_cast<const i32x4*>(Qg + 4096 + m * 2048 + lane * 32 + 16));
     dma_tile(0);
-    if (nkt > 1) dma_tile(1);
+    if (NW == 8 && nkt > 1) dma_tile(1);
     MxFrag kf;
 
     f32x16 o0, o1;
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V with V^T from the ring.
     auto softmax_pv = [&](float (&sv)[16], int kt) __attribute__((always_inline)) {
         const int k0 = kt * 32;
-        const unsigned char* vtile = kv_ring + (size_t)(kt % 3) * SLOTB + TILEB;
+        const unsigned char* vtile = NW == 8 ? kv_ring + (size_t)(kt % 3) * SLOTB + TILEB : kv_ring + TILEB + (size_t)(kt & 1) * TILEB;
         // (the two 32-row halves of V^T one after the other: the second half's fragments are read under the first half's MFMAs —
         //  both resident at once cost 16 registers the loop does not have)
         f16x8 vf[2];
@@ -291,8 +306,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             cq = t[0];
         }
         for (int kt = kt_lo; kt < kt_hi; ++kt) {
-            if (kt + 2 < nkt) dma_tile(kt + 2);
+            if constexpr (NW == 8) { if (kt + 2 < nkt) dma_tile(kt + 2); }
+            else wg_barrier_all();               // Z: key tile kt (K and V^T) is in LDS for everyone
             k_tile(kt, kf);
+            if constexpr (NW == 4) {
+                wg_barrier_lds();                // every wave holds its K fragments: the K slot is free
+                if (kt + 1 < nkt) dma_tile(kt + 1);
+            }
             f32x16 sacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[i] = cq;
@@ -302,11 +322,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
             softmax_pv(sv, kt);
-            wg_barrier_all();
+            if constexpr (NW == 8) wg_barrier_all();
         }
     };
 
-    wg_barrier_all();       // tile 0 is in the ring
+    if constexpr (NW == 8) wg_barrier_all();       // tile 0 is in the ring
     sat_tiles(0, kt_a, a.P - 1);
 
     if (kt_a < kt_b) {
@@ -346,7 +366,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
             const bool extra = (kt % NW) == wave;               // wave-uniform: this wave also computes the block nobody owns
             stamp(-1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // everything requested during tile kt - 1 (rows, offsets, my DMA pieces of tile kt + 1)
+            // everything requested during tile kt - 1 has arrived (rows, offsets, my DMA pieces); NW = 4: barrier Z — key tile kt is in LDS for everyone
+            if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else wg_barrier_all();
             stamp(0);                                           // seg 0: wait for last tile's requests
             MxFrag pk;
             const int od = od_n, odx = odx_n;
@@ -387,7 +409,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             if (extra) band_store(img + c * LROWP + 32 * NW, bacc2);
             wg_barrier_lds();                                   // Y: image complete; tile kt + 1 is in the ring for everyone
             stamp(4);                                           // seg 4: image stores (wait for the p2c MFMA results) + barrier Y
-            dma_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);
+            if constexpr (NW == 8) dma_tile(kt + 2 < nkt ? kt + 2 : nkt - 1);
+            else if (kt + 1 < nkt) dma_tile(kt + 1);           // (the K slot is free since barrier X)
             __builtin_amdgcn_sched_barrier(0);
             float sv[16];
 #pragma unroll
@@ -449,7 +472,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     store_gx(o1, 64 * hh + 32);
 }
 
-constexpr size_t mx_lds_bytes() { return ((size_t)NW * 32 * LROW + 32 * LROWP) * sizeof(float) + 3 * SLOTB; }
 
 // split-f16 units [8 hi | 8 lo] of a Q / K layout tensor (rows in tiles of 32, 64 columns: the position tables at load) -> MX tiles;
 // hl != 0: the tensor travels as (hi8 | lo8) (PQ), else as (lo8 | hi8) (PK).  One thread per (tile, lane slot r): the row's 64 columns.
@@ -481,24 +503,32 @@ __global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* _
 
 // Same contract as glc_launch_attention_wg with split units, except: Qh / Kh / Vt / PQ / PK hold MX tiles (glc_layout.h) and CTX is
 // written as GX rows; otab is the split-unit offset table (engine.hip).  No row selection, no tile flags (the pruned layer keeps its kernel).
-const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a) {
-    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(mx): null pointer";
-    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx): bad shape";
-    if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
-    static std::atomic<unsigned> raised{0};
-    constexpr size_t lds = mx_lds_bytes();
-    static_assert(lds <= 160 * 1024, "LDS budget");
+namespace {
+template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
+    constexpr size_t lds = mx_lds_bytes<NW>();
+    static_assert((NW == 8 ? 1 : 2) * lds <= 160 * 1024, "LDS budget (NW = 4: two workgroups per CU)");
     const int nqb = (a.Sp + 32 * NW - 1) / (32 * NW), bh8 = (a.B * a.nh + 7) / 8 * 8;
     auto go = [&](auto kern, std::atomic<unsigned>& r) -> const char* {
         if (!glc_raise_lds_limit(kern, (int)lds, r)) return "attention(mx): cannot raise the dynamic LDS limit";
         hipLaunchKernelGGL(kern, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
         return nullptr;
     };
-    static std::atomic<unsigned> r1{0}, r2{0}, r4{0};
-    if (a.stamps) return go(attn_mx_kernel<0, true>, r4);
-    if (a.variant & 256) return go(attn_mx_kernel<1>, r1);
-    if (a.variant & 512) return go(attn_mx_kernel<2>, r2);
-    return go(attn_mx_kernel<0>, raised);
+    static std::atomic<unsigned> r0{0}, r1{0}, r2{0}, r4{0};
+    if (a.stamps) return go(attn_mx_kernel<NW, 0, true>, r4);
+    if (a.variant & 256) return go(attn_mx_kernel<NW, 1>, r1);
+    if (a.variant & 512) return go(attn_mx_kernel<NW, 2>, r2);
+    return go(attn_mx_kernel<NW, 0>, r0);
+}
+}  // namespace
+
+const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a) {
+    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(mx): null pointer";
+    if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx): bad shape";
+    if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
+    // workgroup shape (kernel header): 4 waves x two workgroups per CU by default; GLC_ATTN_MX_NW=8 or AttnArgs::variant bit 11: 8 waves x one (bit 10: 4)
+    static const int nw_env = getenv("GLC_ATTN_MX_NW") ? atoi(getenv("GLC_ATTN_MX_NW")) : 4;
+    const int nw = (a.variant & 1024) ? 4 : (a.variant & 2048) ? 8 : nw_env;
+    return nw == 8 ? launch_mx<8>(st, a) : launch_mx<4>(st, a);
 }
 
 // nrows rows (a multiple of 32) x 64 columns x nheads tensors in split units -> MX tiles (position tables at load)

@@ -34,3 +34,29 @@ def test_mx_gemm_every_epilogue_vs_split_gemm(mode, weights_for):
                 assert part_d <= 2e-3 * max(1.0, a_amp), (M, N, K, part_d)              # the LayerNorm partials follow the rows
     finally:
         eng.close()
+
+
+def test_mx_pipeline_odd_batch_shapes():
+    """The MX pipeline (GX projections, MX-tile attention with 4-wave workgroups) on batch shapes the headline does not have: sequence
+    lengths that are no multiple of the workgroup's 128 queries (partly idle workgroups), one query tile per row, long rows, ragged rows
+    — all probabilities against the three-MFMA arithmetic of the same engine (itself <= 2e-5 from the oracle, test_gpu_fullsize.py)."""
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    cfg = CONFIGS["base"]
+    eng = Engine.from_spec(cfg, "synthetic:base:42", dtype="f32")
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    try:
+        eng.set_length_buckets(1)
+        for (B, S, Cn, ragged) in ((300, 192, 3, True), (100, 320, 8, True), (33, 1000, 5, True), (70, 448, 1, False), (17, 2048, 8, True), (1024, 64, 1, False)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=B + S, ragged=ragged)
+            got = eng.forward(ids, mask)
+            assert eng.last_mx() and np.isfinite(got).all(), (B, S)
+            eng.set_mx(False)
+            ref = eng.forward(ids, mask)
+            eng.set_mx(True)
+            assert not np.array_equal(got, ref)
+            d = float(np.abs(sig(got) - sig(ref)).max())
+            assert d <= 3e-4, (B, S, Cn, d)
+    finally:
+        eng.close()

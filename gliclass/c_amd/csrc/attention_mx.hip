@@ -153,12 +153,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         return x + ((glc_pi32(r) - r) << 5);
     };
     auto load_rows = [&](const unsigned char* base, int off, MxFrag& f) __attribute__((always_inline)) {       // gathered table rows: off = split-form offset
-        const unsigned char* pf = base + (off & ~8191) + ((off & 8191) >> 1) + h * 512;
-        const unsigned char* px = base + off + 4096 + h * 1024;
+        // (uniform base + unsigned 32-bit lane offset + immediate: the scalar-base form of global_load, no 64-bit address arithmetic per lane)
+        const unsigned vf = (unsigned)((off & ~8191) + ((off & 8191) >> 1) + h * 512);
+        const unsigned vx = (unsigned)(off + 4096 + h * 1024);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(pf + s * 1024);
+        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(base + (size_t)(vf + (unsigned)(s * 1024)));
 #pragma unroll
-        for (int m = 0; m < 2; ++m) f.x[m] = cat8(*reinterpret_cast<const i32x4*>(px + m * 2048), *reinterpret_cast<const i32x4*>(px + m * 2048 + 16));
+        for (int m = 0; m < 2; ++m)
+            f.x[m] = cat8(*reinterpret_cast<const i32x4*>(base + (size_t)(vx + (unsigned)(m * 2048))), *reinterpret_cast<const i32x4*>(base + (size_t)(vx + (unsigned)(m * 2048 + 16))));
     };
     // ring images: f16 units as they are (16 B per lane), MX steps re-arranged by the DMA into [64 lanes x first | 64 lanes x second]
     auto k_tile = [&](int t, MxFrag& f) __attribute__((always_inline)) {
@@ -213,6 +215,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m = -3.0e38f, l = 0.f;
     const int rr_base = c - 8 * h + 31;
+    float one_f = 1.0f;
+    asm volatile("" : "+s"(one_f));      // opaque to the optimiser: fma(p, 1, -half) stays a v_fma_mix_f32
 
     // Shared tail of every key tile: key bias, online softmax (log2 units, deferred rescale), P*V with V^T from the ring.
     auto softmax_pv = [&](float (&sv)[16], int kt) __attribute__((always_inline)) {
@@ -268,12 +272,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             int wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q], sv[4 * q + 1], 0, false);
             wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q + 2], sv[4 * q + 3], wh, true);
             px[q] = wh;
+            // lo8 = e4m3((p - f16(p)) 2^SHIFT): the residual as ONE mixed-precision FMA per value (p * 1 - f16 half, read from the packed
+            // operand) and the 2^SHIFT inside the conversion (v_cvt_scalef32_pk_fp8_f32 divides by its scale; |residual| 2^SHIFT <= 256: no overflow)
             float r[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (sv[4 * q + e] - (float)pf[q >> 1][4 * (q & 1) + e]) * (float)(1 << GLC_GX_SHIFT);
-            int wl = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
-            wl = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], wl, true);
-            px[4 + q] = wl;
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(sv[4 * q + e], one_f, -(float)pf[q >> 1][4 * (q & 1) + e]);
+            typedef short v2i16 __attribute__((ext_vector_type(2)));
+            v2i16 wl2 = {0, 0};
+            wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[0], r[1], 1.0f / (float)(1 << GLC_GX_SHIFT), false);
+            wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[2], r[3], 1.0f / (float)(1 << GLC_GX_SHIFT), true);
+            px[4 + q] = __builtin_bit_cast(int, wl2);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o0, 0, 0, 0);      // O^T[dd][query c]

@@ -148,6 +148,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         idx = idx < 0 ? 0 : (idx > otab_max ? otab_max : idx);
         return reinterpret_cast<const int*>(a.otab)[2 * idx];
     };
+    auto block_xy = [&](int qb, int t) -> int2 {        // (x, y): the row's offsets in the PQ and in the PK layout (the table holds both)
+        int idx = qb - 32 * t - 31 + c + Sp - 1 + 64;
+        idx = idx < 0 ? 0 : (idx > otab_max ? otab_max : idx);
+        return reinterpret_cast<const int2*>(a.otab)[idx];
+    };
     auto pk_of_pq = [&](int x) -> int {                  // same table row in the K layout: its slot is pi32-permuted
         const int r = (x >> 5) & 31;
         return x + ((glc_pi32(r) - r) << 5);
@@ -157,10 +162,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         const unsigned vf = (unsigned)((off & ~8191) + ((off & 8191) >> 1) + h * 512);
         const unsigned vx = (unsigned)(off + 4096 + h * 1024);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(base + (size_t)(vf + (unsigned)(s * 1024)));
+        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(base + (size_t)vf + s * 1024);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-            f.x[m] = cat8(*reinterpret_cast<const i32x4*>(base + (size_t)(vx + (unsigned)(m * 2048))), *reinterpret_cast<const i32x4*>(base + (size_t)(vx + (unsigned)(m * 2048 + 16))));
+            f.x[m] = cat8(*reinterpret_cast<const i32x4*>(base + (size_t)vx + m * 2048), *reinterpret_cast<const i32x4*>(base + (size_t)vx + (m * 2048 + 16)));
     };
     // ring images: f16 units as they are (16 B per lane), MX steps re-arranged by the DMA into [64 lanes x first | 64 lanes x second]
     auto k_tile = [&](int t, MxFrag& f) __attribute__((always_inline)) {
@@ -253,10 +258,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
         }
-        float psum = 0.f;
+        // (pairs as 2-vectors: v_pk_add_f32 — this file is built without SLP packing, so the pairs are explicit)
+        const f32x2 m2 = {m, m};
+        f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
-        l += psum;
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 d = (f32x2){sv[i], sv[i + 1]} - m2;
+            sv[i] = __builtin_amdgcn_exp2f(d[0]); sv[i + 1] = __builtin_amdgcn_exp2f(d[1]);
+            ps2 += (f32x2){sv[i], sv[i + 1]};
+        }
+        l += ps2[0] + ps2[1];
         // P travels as (hi8 | lo8): f16(p) for the f16 MFMAs (k-step t = keys 16 t + 8 h + j), fp8 parts of the 16 keys for the scaled one
         f16x8 pf[2];
         i32x8 px;
@@ -274,9 +285,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             px[q] = wh;
             // lo8 = e4m3((p - f16(p)) 2^SHIFT): the residual as ONE mixed-precision FMA per value (p * 1 - f16 half, read from the packed
             // operand) and the 2^SHIFT inside the conversion (v_cvt_scalef32_pk_fp8_f32 divides by its scale; |residual| 2^SHIFT <= 256: no overflow)
+            // (inline asm: hipcc converts every value to f16 a second time for a C-level fma(p, 1, -half) instead of reading the halves of the
+            //  packed operand; all three inputs are VALU results — v_exp_f32, an SGPR, v_cvt_pk_f16_f32 — so no LDS / MFMA hazard is involved)
             float r[4];
+            const i32x4 pfw = __builtin_bit_cast(i32x4, pf[q >> 1]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(sv[4 * q + e], one_f, -(float)pf[q >> 1][4 * (q & 1) + e]);
+            for (int e = 0; e < 4; ++e) {
+                const int pw = pfw[2 * (q & 1) + (e >> 1)];
+                if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * q + e]), "s"(one_f), "v"(pw));
+                else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * q + e]), "s"(one_f), "v"(pw));
+            }
             typedef short v2i16 __attribute__((ext_vector_type(2)));
             v2i16 wl2 = {0, 0};
             wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[0], r[1], 1.0f / (float)(1 << GLC_GX_SHIFT), false);
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         MxFrag pq, pqx;
         load_rows(PQg, block_x(q0, kt_a), pq);
         if ((kt_a % NW) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
-        int od_n = block_x(q0, kt_a + 1);
+        int2 od_n = block_xy(q0, kt_a + 1);
         int odx_n = block_x(QX, kt_a + 1);
         unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0, tlast = 0;
         const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -379,8 +397,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             else wg_barrier_all();
             stamp(0);                                           // seg 0: wait for last tile's requests
             MxFrag pk;
-            const int od = od_n, odx = odx_n;
-            od_n = block_x(q0, kt + 2);
+            const int2 od = od_n;
+            const int odx = odx_n;
+            od_n = block_xy(q0, kt + 2);
             odx_n = block_x(QX, kt + 2);
             k_tile(kt, kf);
             float* img = p2c_img;
@@ -406,9 +425,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             stamp(1);                                           // seg 1: K fragments, c2p gather, p2c + S^T MFMA issue
             if (((kt + 1) % NW) == wave) load_rows(PQg, odx, pqx);
             __builtin_amdgcn_sched_barrier(0);
-            load_rows(PKg, pk_of_pq(od), pk);
+            load_rows(PKg, od.y, pk);
             __builtin_amdgcn_sched_barrier(0);
-            load_rows(PQg, od, pq);
+            load_rows(PQg, od.x, pq);
             __builtin_amdgcn_sched_barrier(0);
             stamp(2);                                           // seg 2: row requests (8 waves x 16-24 KB through the CU's vector-memory path)
             wg_barrier_lds();                                   // X: every wave has finished gathering the previous tile's image
@@ -422,10 +441,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             float sv[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 16; i += 2) {
                 const int kc = 16 * (i >> 3) + (i & 7);
                 const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);
-                sv[i] = sacc[i] + img[(prow + 4 * h) * LROWP + 32 * wave + rr_base - kc];
+                const f32x2 g = (f32x2){sacc[i], sacc[i + 1]} +
+                                (f32x2){img[(prow + 4 * h) * LROWP + 32 * wave + rr_base - kc], img[(prow + 1 + 4 * h) * LROWP + 32 * wave + rr_base - kc - 1]};
+                sv[i] = g[0]; sv[i + 1] = g[1];
             }
             f32x16 cacc;
 #pragma unroll

@@ -70,7 +70,9 @@ __device__ __forceinline__ i32x8 cat8(const i32x4& a, const i32x4& b) {
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 
 // ABL: timing-only builds (wrong results; AttnArgs::variant bits 8 / 9 through glc_debug_attn_bench): 1 = without the block-scaled MFMAs,
-// 2 = without the fp8 conversion of the probabilities.
+// 2 = without the fp8 conversion of the probabilities.  ABL = 3 is a MEASUREMENT build with right results at lower precision: P and V^T at
+// single f16 in the P.V product (no P split, no scaled MFMA there) — what the precision budget's one affordable cut buys in
+// time; GLC_ATTN_PV16=1 or variant bit 12, never the default.
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them; the stamps
 // pin the instruction order at each boundary, so the stamped build is slower than the one it describes).
 template <int NW, int ABL = 0, bool DIAG = false>
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             for (int j = 0; j < 8; ++j) pf[t][j] = (f16_t)sv[8 * t + j];
         }
         if constexpr (ABL == 2) { px = qf.x[0]; }
+        else if constexpr (ABL == 3) { }
         else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -303,12 +306,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o0, 0, 0, 0);      // O^T[dd][query c]
-        if constexpr (ABL != 1) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o0, 0, 0, 0, SC, 1, SC);
+        if constexpr (ABL != 1 && ABL != 3) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o0, 0, 0, 0, SC, 1, SC);
         __builtin_amdgcn_sched_barrier(0);
         load_v(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o1, 0, 0, 0);
-        if constexpr (ABL != 1) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o1, 0, 0, 0, SC, 1, SC);
+        if constexpr (ABL != 1 && ABL != 3) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o1, 0, 0, 0, SC, 1, SC);
     };
 
     // key-tile ranges, workgroup-uniform (attention_wg.hip)
@@ -546,6 +549,9 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     if (a.stamps) return go(attn_mx_kernel<NW, 0, true>, r4);
     if (a.variant & 256) return go(attn_mx_kernel<NW, 1>, r1);
     if (a.variant & 512) return go(attn_mx_kernel<NW, 2>, r2);
+    static const bool pv16_env = getenv("GLC_ATTN_PV16") && atoi(getenv("GLC_ATTN_PV16")) != 0;
+    static std::atomic<unsigned> r5{0};
+    if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
     return go(attn_mx_kernel<NW, 0>, r0);
 }
 }  // namespace

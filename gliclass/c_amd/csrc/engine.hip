@@ -1637,7 +1637,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const bool mxk = (variant & 128) != 0;                    // bit 7: the MX-tile kernel (attention_mx.hip) on the MX tiles the last (MX) forward left; bits 8 / 9: its timing-only builds
     if (mxk) {
         if (!(sp && e->last_mx && e->mx_attn && w.PKm && w.PQm)) { set_err("attn_bench: the MX kernel needs a previous forward of the MX pipeline with MX attention"); return -1.f; }
-        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048);
+        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048 | 4096);
     }
     auto launch = [&]() -> const char* { return mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
     for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);

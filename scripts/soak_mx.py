@@ -1,7 +1,7 @@
 """Developer tool (GPU): soak of the default (MX) pipeline — random batch shapes on the base model for a few minutes, every forward run
 twice (bit-identical logits expected: same shapes, same kernels, fixed accumulation orders; a synchronisation hazard in the LDS rings /
 images of gemm256x.hip or attention_mx.hip would show as a mismatch) and, every few rounds, rows checked against the three-MFMA arithmetic
-(GLICLASS_MX=0) within the test tolerance.  usage: soak_mx.py [seconds]"""
+(GLICLASS_MX=0) within the test tolerance.  usage: soak_mx.py [seconds] [config]"""
 import os, sys, time, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,8 +10,9 @@ from gliclass.c_amd.config import CONFIGS
 from gliclass.c_amd import synth
 from gliclass.c_amd.engine import Engine
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
-cfg = CONFIGS["base"]
-e = Engine.from_spec(cfg, "synthetic:base:42", dtype="f32")
+cname = sys.argv[2] if len(sys.argv) > 2 else "base"
+cfg = CONFIGS[cname]
+e = Engine.from_spec(cfg, f"synthetic:{cname}:42", dtype="f32")
 rng = np.random.RandomState(20261004)
 sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
 t0 = time.time(); rounds = 0; mism = 0; worst = 0.0; mx_rounds = 0

@@ -381,8 +381,8 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                             const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
                             const int tile = bh * (p.Sp >> 5) + (sq >> 5), slot = which == 0 ? (sq & 31) : glc_pi32(sq & 31);
                             unsigned char* bq = reinterpret_cast<unsigned char*>(which == 0 ? p.Qh : p.Kh);
-                            *reinterpret_cast<vec8T*>(bq + glc_mxt_f16(tile, slot, dd)) = o;
                             unsigned char* px = bq + glc_mxt_mx(tile, slot, dd);
+                            *reinterpret_cast<vec8T*>(bq + glc_mxt_f16(tile, slot, dd)) = o;
                             *reinterpret_cast<u32x2*>(px) = which == 0 ? h8 : l8;
                             *reinterpret_cast<u32x2*>(px + 16) = which == 0 ? l8 : h8;
                             continue;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo);
+                    } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo);      // FFN1's intermediate: streams (non-temporal)
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                         const u32x2 h8 = {glc_fp8x4(x8[0], x8[1], x8[2], x8[3]), glc_fp8x4(x8[4], x8[5], x8[6], x8[7])};
                         const int tile = (b * p.nh + hh) * (p.Sp >> 5) + (sq >> 5);
                         unsigned char* bv = reinterpret_cast<unsigned char*>(p.Vt);
-                        *reinterpret_cast<vec8T*>(bv + glc_mxt_v_f16(tile, dd, sq)) = o;
                         unsigned char* px = bv + glc_mxt_v_mx(tile, dd, sq);
+                        *reinterpret_cast<vec8T*>(bv + glc_mxt_v_f16(tile, dd, sq)) = o;
                         *reinterpret_cast<u32x2*>(px) = l8;
                         *reinterpret_cast<u32x2*>(px + 16) = h8;
                         continue;

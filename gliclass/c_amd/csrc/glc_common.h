@@ -178,17 +178,25 @@ __device__ __forceinline__ uint32_t glc_fp8x4(float a, float b, float c, float d
     return (uint32_t)w;
 }
 // eight consecutive elements e0 .. e0 + 7 (e0 % 8 == 0) of a GX row; `row` = the row's first byte; k_hi = 2^sc, k_lo = 2^(sc + SHIFT)
-template <bool WORDER = false>
+// NT: non-temporal stores — for an output that streams to HBM and is too large for the caches to keep until its reader runs (FFN1's 805 MB
+// intermediate at c3): it then does not evict the operand panels the same launch is still re-reading (FFN1 + GELU 750 -> 717 us).
+template <bool WORDER = false, bool NT = false>
 __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const float (&v)[8], float k_hi, float k_lo) {
     gs_h8 hi;
     float l[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; l[e] = (v[e] - (float)h) * k_lo; }
     unsigned char* p = row + (e0 >> 5) * 128;
-    *reinterpret_cast<gs_h8*>(p + (e0 & 31) * 2) = hi;
     const uint32_t l0 = glc_fp8x4(l[0], l[1], l[2], l[3]), l1 = glc_fp8x4(l[4], l[5], l[6], l[7]);
     const uint32_t h0 = glc_fp8x4(v[0] * k_hi, v[1] * k_hi, v[2] * k_hi, v[3] * k_hi), h1 = glc_fp8x4(v[4] * k_hi, v[5] * k_hi, v[6] * k_hi, v[7] * k_hi);
-    *reinterpret_cast<u32x4*>(p + 64 + (e0 & 31) * 2) = WORDER ? (u32x4){h0, h1, l0, l1} : (u32x4){l0, l1, h0, h1};
+    const u32x4 x8 = WORDER ? (u32x4){h0, h1, l0, l1} : (u32x4){l0, l1, h0, h1};
+    if constexpr (NT) {
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, hi), reinterpret_cast<u32x4*>(p + (e0 & 31) * 2));
+        __builtin_nontemporal_store(x8, reinterpret_cast<u32x4*>(p + 64 + (e0 & 31) * 2));
+    } else {
+        *reinterpret_cast<gs_h8*>(p + (e0 & 31) * 2) = hi;
+        *reinterpret_cast<u32x4*>(p + 64 + (e0 & 31) * 2) = x8;
+    }
 }
 // x = hi + lo8 * inv_lo, inv_lo = 2^-(sc + SHIFT)
 __device__ __forceinline__ void gx_decode8(const gs_h8& hi, const u32x2& lo8, float inv_lo, float (&v)[8]) {

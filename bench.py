@@ -260,7 +260,7 @@ def cpu_baseline(cfg, wptrs, S, C_labels, seqs, seqs8):
     return out, logits, ids, mask
 
 
-def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, config_key, mx=False):
+def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, config_key, mx=False, mx_attn=False):
     """Per-kernel-class HIP-event profile of 3 forwards on the engine's stream -> the `roofline` object."""
     fl = kernel_flops(cfg, B, S)
     hipl.glc_profile_enable(h, 1)
@@ -297,9 +297,22 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
             traffic_src = "profiles/traffic.json (" + ent.get("source", "?") + ")"
     except Exception:
         pass
-    mpp = MFMA_PER_PRODUCT[dtype]
-    if mx and dom.startswith("gemm"):
-        mpp = 2                    # MX projections: a_hi*w_hi as f16 MFMAs + both cross terms as one fp8 MFMA at twice the f16 rate (attention stays at 3)
+    # matrix-pipe time per product in f16-MFMA units, per kernel class.  MX (projections; attention when it runs on MX tiles): a_hi*w_hi as
+    # f16 MFMAs + both cross terms as one block-scaled fp8 MFMA at twice the f16 rate = 2; split-f16 units = 3; 16-bit modes = 1
+    def units(name):
+        if dtype != "f32":
+            return MFMA_PER_PRODUCT[dtype]
+        if name.startswith("gemm"):
+            return 2 if mx else 3
+        if name == "attention":
+            return 2 if (mx and mx_attn) else 3
+        return 3
+    mpp = units(dom)
+    # whole-forward matrix-pipe occupancy: every class at its own unit count, weighted by its algorithmic FLOPs per forward
+    # (the pruned last layer and the head run split-f16 units; they are < 3 % of the FLOPs)
+    w_fl = sum(fl[n] * per[n]["launches_per_fwd"] * units(n) for n in per if n in fl)
+    a_fl = sum(fl[n] * per[n]["launches_per_fwd"] for n in per if n in fl)
+    mpp_fwd = w_fl / a_fl if a_fl > 0 else mpp
     return dict(bound="mfma", kernel=dom, achieved=per[dom]["tflops"], peak=peak, unit="TFLOP/s",
                 frac=round(per[dom]["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_src,
                 flops_per_launch=fl[dom], avg_launch_ms=per[dom]["avg_ms"],
@@ -309,7 +322,8 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
                 # matrix-pipe occupancy of the whole forward, NOT an efficiency figure: the FLOPs the pipes execute — every product of
                 # this mode costs mfma_per_product MFMAs, i.e. x3 self-inflicted work in the default mode — over the f16 peak.  The
                 # number that counts against the north star is e2e_frac (algorithmic FLOPs).
-                executed_mfma_whole_forward_frac=round(executed * mpp / peak, 4), per_kernel=per)
+                mfma_units_whole_forward=round(mpp_fwd, 3),
+                executed_mfma_whole_forward_frac=round(executed * mpp_fwd / peak, 4), per_kernel=per)
 
 
 def prob_err(a, b):
@@ -473,8 +487,9 @@ def main():
             key = f"{args.config}:{args.batch}:{S}"
             roof = None
             mx_on = bool(hipl.glc_debug_last_forward_mx(h)) if args.dtype == "f32" else False
+            mx_attn_on = bool(hipl.glc_debug_last_forward_mx_attention(h)) if mx_on else False
             if not args.no_profile:
-                roof = profile_mode(hipl, h, runner.step, runner.sync, cfg, B, S, Cn, args.dtype, B / (ev_ms * 1e-3), key, mx_on)
+                roof = profile_mode(hipl, h, runner.step, runner.sync, cfg, B, S, Cn, args.dtype, B / (ev_ms * 1e-3), key, mx_on, mx_attn_on)
             # boundary-inclusive step (SURVEY.md §8d protocol): host int64 ids/mask in, H2D, forward, D2H of the logits out
             host_ms = None
             if world == 1:
@@ -493,7 +508,8 @@ def main():
                 n = rids.shape[0]
                 cpu["gpu_vs_cpu_max_prob_err"] = prob_err(logits[:n], ref_logits)
                 cpu["rows_compared"] = n
-            mode_txt = {"f32": ("f32 data; projections: a_hi*w_hi in f16 MFMAs + both cross terms in one block-scaled fp8 MFMA (MX, ~2^-15 per product); attention: split-f16 x3 MFMA products (the product's default mode)"
+            mode_txt = {"f32": ("f32 data; every product a_hi*w_hi in f16 MFMAs + both cross terms in one block-scaled fp8 MFMA (MX, ~2^-15 per product); projections: gemm256x on GX rows; attention: "
+                                + ("attention_mx on MX tiles" if mx_attn_on else "split-f16 x3 MFMA products (GLC_MX_ATTN=0)") + " (the product's default mode)"
                                 if mx_on else "f32 data, split-f16 x3 MFMA products (the default mode with GLICLASS_MX=0, or a forward too small for the 256-tile pipeline)"), "f16": "f16 MFMA operands (opt-in throughput mode)",
                         "bf16": "bf16 MFMA operands (opt-in throughput mode)"}[args.dtype]
             shape_txt = (f"gliclass-{args.config} (DeBERTa-v3 shape L={cfg.layers} H={cfg.hidden})" if cfg.backbone != 1 else
@@ -502,7 +518,7 @@ def main():
                 "metric": f"sequences/sec at batch={args.batch} seq={S}, gliclass-{args.config}; %MFMA-peak",
                 "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-                "dtype": args.dtype, "mode": mode_txt, "mx_projections": mx_on, "data": "synthetic",
+                "dtype": args.dtype, "mode": mode_txt, "mx_projections": mx_on, "mx_attention": mx_attn_on, "data": "synthetic",
                 "config": {"workload": f"{shape_txt}, batch={args.batch} seq={S} labels={Cn}, random-init weights (seed 42), full-length rows",
                            "global_batch": global_rows, "seq_len": S,
                            "parallelism": (f"batch-shard x{world}: one process per GPU, every rank a full batch, no data-path collective" if args.scaling == "weak" else

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
                 v[e] = h ? got : own_a;
                 v[4 + e] = h ? own_b : got;
             }
-            gx_store8(row, col0 + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT));
+            gx_store8(row, col0 + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), a.gx_sat);
         }
     };
     store_gx(o0, 64 * hh);
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
 
 // split-f16 units [8 hi | 8 lo] of a Q / K layout tensor (rows in tiles of 32, 64 columns: the position tables at load) -> MX tiles;
 // hl != 0: the tensor travels as (hi8 | lo8) (PQ), else as (lo8 | hi8) (PK).  One thread per (tile, lane slot r): the row's 64 columns.
-__global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int ntiles, int hl) {
+__global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int ntiles, int hl, unsigned* sat) {
     const int tile = blockIdx.x, r = threadIdx.x & 31, half = threadIdx.x >> 5;      // half: columns 32 half .. 32 half + 31
     if (tile >= ntiles) return;
     const unsigned char* st = src + (size_t)tile * 8192;
@@ -519,6 +519,7 @@ __global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* _
         gs_h8 hi;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { hi[j] = u[j]; v[j] = (float)u[j] + (float)u[8 + j]; }
+        gx_range_note(v, 1.0f, sat);
         *reinterpret_cast<gs_h8*>(dt + glc_mxt_f16(0, r, 8 * g)) = hi;
         float lo[8];
 #pragma unroll
@@ -556,7 +557,9 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
 }
 }  // namespace
 
-const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a) {
+const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a_in) {
+    AttnArgs a = a_in;
+    if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the GX context rows
     if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(mx): null pointer";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx): bad shape";
     if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
@@ -567,8 +570,8 @@ const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a) {
 }
 
 // nrows rows (a multiple of 32) x 64 columns x nheads tensors in split units -> MX tiles (position tables at load)
-const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl) {
+const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat) {
     if (!src || !dst || ntiles <= 0) return "units_to_mxt: bad args";
-    hipLaunchKernelGGL(units_to_mxt_kernel, dim3(ntiles), dim3(64), 0, st, (const unsigned char*)src, (unsigned char*)dst, ntiles, hl);
+    hipLaunchKernelGGL(units_to_mxt_kernel, dim3(ntiles), dim3(64), 0, st, (const unsigned char*)src, (unsigned char*)dst, ntiles, hl, sat);
     return nullptr;
 }

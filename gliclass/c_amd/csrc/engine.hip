@@ -80,6 +80,7 @@ struct glc_engine {
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
     bool mx_built = false, mx = false;   // MX cross-term projections (gemm256x.hip) on GX rows: weights present / pipeline selected (GLICLASS_MX, glc_debug_set_mx)
     bool last_mx = false;                // the last forward ran the MX pipeline
+    bool last_mx_attn = false;           // ... and its attention ran on MX tiles (attention_mx.hip)
     bool mx_attn = true;                 // MX pipeline: attention on MX tiles (attention_mx.hip); false: split-f16 units (GLC_MX_ATTN=0, glc_debug_set_mx_attention)
     int debug_stop = -1;                 // developer: leave run_forward after stage (10 * layer + k), k = 0 QKV, 1 attention, 2 attn-out, 3 FFN1, 4 FFN2 (+ LayerNorm): workspace inspection
     int prec_mask = 0;              // precision-budget switches (PM_* of glc_kernels.h; glc_debug_set_precision_mask): operands rounded to f16 in the group-split pipeline
@@ -91,6 +92,11 @@ struct glc_engine {
     int max_buckets = 4;            // host-buffer forward: split a ragged batch into <= this many length groups (1 = off)
     int last_groups = 1;            // groups the last host-buffer forward ran as
     int range_retries = 0;          // host-buffer forwards repeated with the norms unfused because the folded one came out non-finite
+    // fp8 range guard of the MX pipeline (glc_common.h gx_range_note): device counter of activation elements beyond the e4m3 range, its value after the
+    // last checked forward, a pinned host slot for the device-resident path; forwards repeated on the split-f16 kernels because they counted
+    // any; consecutive such forwards (the model has outlier channels: after kFp8Sticky of them the engine leaves the MX pipeline for good)
+    unsigned* d_gxsat = nullptr; unsigned gxsat_seen = 0; unsigned* h_gxsat = nullptr;
+    int fp8_retries = 0, fp8_streak = 0; bool fp8_sticky_off = false, fp8_device_pending = false;
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -118,6 +124,9 @@ struct glc_engine {
     std::map<int, int32_t*> dtabs;
     std::map<int, int2*> otabs;                // Sp -> byte offsets of the PQ / PK rows per relative distance (band kernel, 16-bit)
     std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
+    std::map<int, std::pair<void*, int4*>> mx2tabs;   // Sp -> (idx16, tinfo) of attention_mx2.hip; (null, null): this table keeps the band kernel
+    bool mx2 = false;                          // MX attention on the bucket-space kernel (attention_mx2.hip; needs its tables) instead of the band kernel (attention_mx.hip): opt-in
+                                               // (GLC_ATTN_MX2=1, glc_debug_set_mx2) — measured 4-5 % slower at c3
     // last forward
     int lastB = 0, lastS = 0, lastSp = 0;
     // debug
@@ -186,8 +195,18 @@ bool upload_as(glc_engine* e, const float* src, size_t n, void* dst, float* stag
     return hipStreamSynchronize(e->stream) == hipSuccess;   // staging is reused by the caller
 }
 
+constexpr int kFp8Sticky = 2;
+bool init_range_guard(glc_engine* e) {
+    if (e->d_gxsat) return true;
+    e->d_gxsat = (unsigned*)dmalloc(e, sizeof(unsigned), false);
+    if (!e->d_gxsat || hipMemset(e->d_gxsat, 0, sizeof(unsigned)) != hipSuccess) { set_err("range-guard counter alloc failed"); return false; }
+    if (hipHostMalloc((void**)&e->h_gxsat, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { e->h_gxsat = nullptr; set_err("range-guard host slot alloc failed"); return false; }
+    *e->h_gxsat = 0;
+    return true;
+}
 bool ensure_capacity(glc_engine* e, int B, int S, int C) {
     const glc_model_config& c = e->cfg;
+    if (!init_range_guard(e)) return false;
     if (!e->splitk_ws) {
         e->splitk_ws_bytes = (size_t)64 << 20;
         e->splitk_ws = (float*)dmalloc(e, e->splitk_ws_bytes, false);
@@ -322,6 +341,18 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
         for (int r = Sp - 1; r >= -(Sp - 1) && t[r + Sp - 1] == 2 * (c.pos_buckets > 0 ? c.pos_buckets : c.max_rel_pos) - 1; --r) rp = r;
         for (int r = -(Sp - 1); r <= Sp - 1 && t[r + Sp - 1] == 0; ++r) rn = r;
         e->dsat[Sp] = std::make_pair(rp, rn);
+        // tables of the bucket-space MX attention (attention_mx2.hip); a table without the structure it needs keeps the band kernel
+        std::vector<unsigned char> idx16;
+        std::vector<int4> tinfo;
+        void* d_idx = nullptr; int4* d_ti = nullptr;
+        if (e->dtype == GLC_F32 && glc_mx2_build_tables(Sp, e->P, t.data(), idx16, tinfo)) {
+            d_idx = dmalloc(e, idx16.size(), false);
+            d_ti = (int4*)dmalloc(e, tinfo.size() * sizeof(int4), false);
+            if (!d_idx || !d_ti) return false;
+            if (hipMemcpy(d_idx, idx16.data(), idx16.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_ti, tinfo.data(), tinfo.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { set_err("mx2 table upload failed"); return false; }
+        }
+        e->mx2tabs[Sp] = std::make_pair(d_idx, d_ti);
     }
     return true;
 }
@@ -379,6 +410,10 @@ bool run_head_tail(glc_engine* e, int B, int C, float* d_logits) {
     KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, h), false);
     const float* Tt = e->G2t;
     const float* Cc = e->G2t + (size_t)rt * H;
+    // normalize_features (upstream: projected text and class features are L2-normalised before ANY scorer and the logits multiplied by
+    // logit_scale): the dot scorer does both inside its kernel; the other scorers get a row pass over G2 and the scale in their last step
+    const float lscale = c.normalize_features ? c.logit_scale : 1.0f;
+    if (c.scorer != GLC_SCORER_DOT && c.normalize_features) KCHK(glc_launch_l2norm_rows(st, e->G2t, rt + rc, H), false);
     if (c.scorer == GLC_SCORER_DOT) {
         KCHK(glc_launch_head_score(st, Tt, Cc, d_logits, B, C, H, c.normalize_features, c.logit_scale), false);
     } else if (c.scorer == GLC_SCORER_WEIGHTED_DOT) {
@@ -393,7 +428,7 @@ bool run_head_tail(glc_engine* e, int B, int C, float* d_logits) {
         GemmArgs o;
         o.N = 4 * H; o.K = 3 * H; o.Mpad = rc; o.A = cat; o.W = e->scw[4]; o.bias = e->scw[5]; o.C = hid;
         KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, o), false);
-        KCHK(glc_launch_relu_dot(st, hid, e->scw[6], e->scw[7], d_logits, B * C, 4 * H), false);
+        KCHK(glc_launch_relu_dot(st, hid, e->scw[6], e->scw[7], d_logits, B * C, 4 * H, lscale), false);
     } else {
         const int Mh = GLC_SCORER_MLP_HIDDEN;
         float* pair = e->scorer_ws;                              // [rc, 2H] = [text | class]
@@ -407,7 +442,7 @@ bool run_head_tail(glc_engine* e, int B, int C, float* d_logits) {
         GemmArgs g2;
         g2.N = Mh / 2; g2.K = Mh; g2.Mpad = rc; g2.A = h1; g2.W = e->scw[2]; g2.bias = e->scw[3]; g2.C = h2;
         KCHK(launch_gemm128(e, GLC_F32, EPI_BIAS, g2), false);
-        KCHK(glc_launch_relu_dot(st, h2, e->scw[4], e->scw[5], d_logits, B * C, Mh / 2), false);
+        KCHK(glc_launch_relu_dot(st, h2, e->scw[4], e->scw[5], d_logits, B * C, Mh / 2, lscale), false);
     }
     return true;
 }
@@ -423,6 +458,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     const size_t es = esize(dt);
     const int ccap = e->capC > 0 ? e->capC : 1;
     if (e->profile) { e->ev_used = 0; }
+    glc_gx_sat_ptr() = e->d_gxsat;           // fp8 range guard: the launchers of this thread hand the counter to every producer of GX rows / MX tiles
     if (e->keep_hidden) {
         const size_t need = (size_t)(L + 1) * M * H * es;
         if (need > e->hidden_cap) { dfree(e, e->hidden_dump); e->hidden_dump = dmalloc(e, need); if (!e->hidden_dump) return false; e->hidden_cap = need; }
@@ -455,6 +491,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     bool mx = rnf && e->mx && e->mx_built && e->prec_mask == 0;
     for (int l = 0; mx && l < L; ++l) mx = e->dlayers[l].Wqkvf_x && e->dlayers[l].Wo_x && e->dlayers[l].Wguf_x && e->dlayers[l].Wd_x;
     e->last_mx = mx;
+    e->last_mx_attn = false;
     auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* { return mx ? glc_launch_gemm256x(st, epi, ga) : glc_launch_gemm256s_gs(st, epi, ga); };
     if (rnf) {      // the embedding rows enter the pipeline: plain fp32 (X2) -> raw group-split rows (X) + statistics
         HIPCHK(hipMemcpyAsync(e->X2, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
@@ -535,6 +572,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     const size_t es = esize(dt);
     const int ccap = e->capC > 0 ? e->capC : 1;
     if (e->profile) { e->ev_used = 0; }
+    glc_gx_sat_ptr() = e->d_gxsat;           // fp8 range guard (see run_forward_decoder)
 
     if (e->keep_hidden) {
         const size_t need = (size_t)(c.layers + 1) * M * H * es;
@@ -571,6 +609,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     bool mx = gs && e->mx && e->mx_built && e->ln_fused && e->prec_mask == 0 && c.layers >= 2;
     for (int l = 0; mx && l < c.layers; ++l) mx = e->layers[l].W1f_x && e->layers[l].Wqkv_x && e->layers[l].Wo_x && e->layers[l].W2_x && (l == 0 || e->layers[l].Wqkvf_x);
     e->last_mx = mx;
+    e->last_mx_attn = false;
     auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* { return mx ? glc_launch_gemm256x(st, epi, ga) : glc_launch_gemm256s_gs(st, epi, ga); };
     // 16-bit modes: the same LayerNorm fold on plain rows of T, when all four projections of a layer run on the staggered 256-tile kernel
     bool fold16 = false;
@@ -603,14 +642,16 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         const int pm = gs ? e->prec_mask : 0;
         g.prec = pm & 3;
         { Prof p(e, PC_QKV); KCHK(gs ? gemm_gs(EPI_QKV, g) : launch_gemm_auto(e, dt, EPI_QKV, g), false); }
+        if (e->debug_stop >= 10 * l && e->debug_stop <= 10 * l + 4) { e->lastB = B; e->lastS = S; e->lastSp = Sp; }      // (a stopped forward still describes the workspace it leaves)
         if (e->debug_stop == 10 * l + 0) return true;
         AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         a.split = asplit; a.ctx_gs = mx ? 2 : (gs ? 1 : 0); a.prec = (pm >> 8) & 63;
         static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
-        if (mxa) { a.PK = w.PKm; a.PQ = w.PQm; }
-        { Prof p(e, PC_ATTN); KCHK(mxa ? glc_launch_attention_mx(st, a) : launch_band(a), false); }
+        if (mxa) { a.PK = w.PKm; a.PQ = w.PQm; e->last_mx_attn = true; a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second; }
+        const bool mxa2 = mxa && e->mx2 && a.idx16 && a.tinfo;      // bucket-space kernel (round 4) when this length's table has the structure it needs
+        { Prof p(e, PC_ATTN); KCHK(mxa2 ? glc_launch_attention_mx2(st, a) : mxa ? glc_launch_attention_mx(st, a) : launch_band(a), false); }
         if (e->debug_stop == 10 * l + 1) return true;
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
@@ -910,6 +951,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         e->mx_built = eligible && !(mv && !strcmp(mv, "0"));
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
         if (const char* av = getenv("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
+        if (const char* av = getenv("GLC_ATTN_MX2")) e->mx2 = atoi(av) != 0;         // developer A/B switch: 1 = the bucket-space kernel (attention_mx2.hip)
     }
     if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
@@ -1070,9 +1112,13 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 if (lok && w.PKs && w.PQs) {      // the position tables as MX tiles: PQ travels as (hi8 | lo8), PK as (lo8 | hi8)
                     w.PKm = dmalloc(e, (size_t)nh * P * 64 * es);
                     w.PQm = dmalloc(e, (size_t)nh * P * 64 * es);
-                    const char* pm = (w.PKm && w.PQm) ? glc_launch_units_to_mxt(e->stream, w.PKs, w.PKm, nh * (P / 32), 0) : "MX position tables: allocation failed";
-                    if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PQs, w.PQm, nh * (P / 32), 1);
+                    // (fp8 range guard at load: a table value beyond the e4m3 range keeps this layer's attention on split units)
+                    unsigned seen = 0;
+                    const char* pm = !init_range_guard(e) ? "range guard: allocation failed" : (w.PKm && w.PQm) ? glc_launch_units_to_mxt(e->stream, w.PKs, w.PKm, nh * (P / 32), 0, e->d_gxsat) : "MX position tables: allocation failed";
+                    if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PQs, w.PQm, nh * (P / 32), 1, e->d_gxsat);
+                    if (!pm && (hipMemcpyAsync(&seen, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)) pm = "MX position tables: readback failed";
                     if (pm) { set_err(pm); lok = false; }
+                    else if (seen != e->gxsat_seen) { e->gxsat_seen = seen; dfree(e, w.PKm); dfree(e, w.PQm); w.PKm = w.PQm = nullptr; }
                 }
                 if (!lok) break;
             }
@@ -1100,6 +1146,7 @@ void glc_engine_destroy(glc_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->allocs) (void)hipFree(p);
+    if (e->h_gxsat) (void)hipHostFree(e->h_gxsat);
     for (auto& v : e->evs) { (void)hipEventDestroy(v.a); (void)hipEventDestroy(v.b); }
     if (e->t0) (void)hipEventDestroy(e->t0);
     if (e->t1) (void)hipEventDestroy(e->t1);
@@ -1119,20 +1166,47 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
     // pre-norm decoder's massive-activation channels can leave the f16 range although every normalised row is tiny — so a non-finite
     // result of a folded forward is retried ONCE with the norms as kernels of their own (residual stream plain fp32, only normalised
     // rows split); what is still non-finite then fails the call.  (fp32 mode: GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native run the fp32 MFMAs.)
-    const bool fused_saved = e->ln_fused;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) { e->ln_fused = fused_saved; return -1; }
+    // fp8 range (round 4): the MX pipeline's operand images carry e4m3 parts with exponent 0; an activation beyond 448 saturates there and that
+    // element's cross terms fall to single-f16 accuracy without any error.  Every producer counts such elements (glc_common.h gx_range_note);
+    // a forward that counted any is repeated ONCE on the split-f16 kernels (operands up to 65504, the LayerNorm fold kept).  After kFp8Sticky
+    // consecutive forwards that needed it the engine leaves the MX pipeline for good: the model has outlier channels, paying twice per forward is pointless.
+    struct Restore {      // every exit path puts the engine's switches back (a HIP error inside a retry must not leave it unfused / off MX)
+        glc_engine* e; bool fused, mx;
+        ~Restore() { e->ln_fused = fused; e->mx = mx; }
+    } restore{e, e->ln_fused, e->mx};
+    if (e->fp8_sticky_off) e->mx = false;
+    unsigned sat_now = e->gxsat_seen;
+    bool tried_unfused = false, tried_split = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) return -1;
         HIPCHK(hipMemcpyAsync(cnt, e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
         if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
+        HIPCHK(hipMemcpyAsync(&sat_now, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), -1);
         HIPCHK(hipStreamSynchronize(e->stream), -1);
-        if (e->profile) prof_collect(e);
         bool finite = true;
         for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n && finite; ++i) finite = isfinite(logits[i]);
-        if (finite || attempt == 1 || !(e->dtype == GLC_F32 && e->last_lnf)) break;
-        e->ln_fused = false;                // retry: norms unfused
-        e->range_retries++;
+        const bool sat = sat_now != e->gxsat_seen;
+        e->gxsat_seen = sat_now;
+        if (!finite && !tried_unfused && e->dtype == GLC_F32 && e->last_lnf) {
+            tried_unfused = true;
+            e->ln_fused = false;            // retry: norms unfused (this also leaves the MX pipeline)
+            e->range_retries++;
+            continue;
+        }
+        if (finite && sat && e->last_mx && !tried_split) {
+            tried_split = true;
+            e->mx = false;                  // retry: three f16 MFMAs per product, operands up to 65504
+            e->fp8_retries++;
+            if (++e->fp8_streak >= kFp8Sticky && !e->fp8_sticky_off) {
+                e->fp8_sticky_off = true;
+                fprintf(stderr, "gliclass: activations beyond the fp8 range of the MX operand images (|x| > 448) in %d consecutive forwards; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0)\n", e->fp8_streak);
+            }
+            continue;
+        }
+        if (e->last_mx && !sat) e->fp8_streak = 0;
+        break;
     }
-    e->ln_fused = fused_saved;
+    if (e->profile) prof_collect(e);        // (the attempt whose result is returned)
     for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n; ++i)
         if (!isfinite(logits[i])) {
             set_err("forward: non-finite logit (row " + std::to_string(i / c_alloc) + "): an activation left the range of the " +
@@ -1267,6 +1341,9 @@ int glc_plan_length_buckets(const int* lengths, int B, int max_groups, int hidde
 
 int glc_debug_last_forward_groups(const glc_engine* e) { return e ? e->last_groups : -1; }
 int glc_debug_range_retries(const glc_engine* e) { return e ? e->range_retries : -1; }
+int glc_debug_fp8_range_retries(const glc_engine* e) { return e ? e->fp8_retries : -1; }
+int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_off ? 1 : 0) : -1; }
+int glc_debug_set_mx2(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx2 = on != 0; return 0; }
 
 int glc_engine_set_length_buckets(glc_engine* e, int max_groups) {
     if (!e || max_groups < 1 || max_groups > 64) { set_err("set_length_buckets: 1..64 groups"); return -1; }
@@ -1280,14 +1357,33 @@ int glc_engine_forward_device(glc_engine* e, const void* d_ids, const void* d_ma
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHK(hipSetDevice(e->device), -1);
     if (!ensure_capacity(e, B, S, C)) return -1;
-    return run_forward(e, (const int64_t*)d_ids, (const int64_t*)d_mask, B, S, C, (float*)d_logits) ? 0 : -1;
+    const bool mx_saved = e->mx;
+    if (e->fp8_sticky_off) e->mx = false;
+    const bool ok = run_forward(e, (const int64_t*)d_ids, (const int64_t*)d_mask, B, S, C, (float*)d_logits);
+    e->mx = mx_saved;
+    if (!ok) return -1;
+    // fp8 range guard (forward_one): a device-resident forward cannot be repeated behind the caller's back — the counter travels to a pinned
+    // slot behind it, and glc_engine_sync reports a forward that left the range (and moves the engine to the split arithmetic)
+    if (e->last_mx) { HIPCHK(hipMemcpyAsync(e->h_gxsat, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), -1); e->fp8_device_pending = true; }
+    return 0;
 }
 
 int glc_engine_sync(glc_engine* e) {
     if (!e) { set_err("sync: null engine"); return -1; }
     HIPCHK(hipSetDevice(e->device), -1);
     HIPCHK(hipStreamSynchronize(e->stream), -1);
-    if (e->profile) { std::lock_guard<std::mutex> lk(e->mu); prof_collect(e); }
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->profile) prof_collect(e);
+    if (e->fp8_device_pending) {
+        e->fp8_device_pending = false;
+        if (*e->h_gxsat != e->gxsat_seen) {
+            e->gxsat_seen = *e->h_gxsat;
+            e->fp8_sticky_off = true;
+            set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images (|x| > 448): its logits are at "
+                    "single-f16 accuracy in those elements; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0) — run the forward again");
+            return -1;
+        }
+    }
     return 0;
 }
 
@@ -1357,9 +1453,11 @@ int glc_debug_set_mx(glc_engine* e, int on) {
     if (on && !e->mx_built) { set_err("set_mx: this engine was created without the GX weight copies (GLICLASS_MX=1 or =build)"); return -1; }
     std::lock_guard<std::mutex> lk(e->mu);
     e->mx = on != 0;
+    if (on) { e->fp8_sticky_off = false; e->fp8_streak = 0; }      // (a developer switching MX back on also clears the range guard's verdict)
     return 0;
 }
 int glc_debug_last_forward_mx(const glc_engine* e) { return e ? (e->last_mx ? 1 : 0) : -1; }
+int glc_debug_last_forward_mx_attention(const glc_engine* e) { return e ? (e->last_mx && e->last_mx_attn ? 1 : 0) : -1; }
 /* MX pipeline: attention on MX tiles (1, default) or on split-f16 units (0). */
 int glc_debug_set_mx_attention(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx_attn = on != 0; return 0; }
 /* Developer: stop the next forwards after stage 10 * layer + k (k = 0 QKV, 1 attention, 2 attention-output, 3 FFN1, 4 FFN2 + LayerNorm;
@@ -1638,8 +1736,11 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     if (mxk) {
         if (!(sp && e->last_mx && e->mx_attn && w.PKm && w.PQm)) { set_err("attn_bench: the MX kernel needs a previous forward of the MX pipeline with MX attention"); return -1.f; }
         a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048 | 4096);
+        a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second;
     }
-    auto launch = [&]() -> const char* { return mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
+    const bool mxk2 = mxk && (variant & 8192) != 0;           // bit 13: the bucket-space MX kernel (attention_mx2.hip)
+    if (mxk2 && !(a.idx16 && a.tinfo)) { set_err("attn_bench: no mx2 tables for this length"); return -1.f; }
+    auto launch = [&]() -> const char* { return mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
     for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);
     for (int i = 0; i < iters; ++i) launch();
@@ -1688,7 +1789,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
             (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
             AttnArgs as = a; as.stamps = dbuf;
-            const char* m = glc_launch_attention_mx(st, as);
+            const char* m = mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
             (void)hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(ns);
             if (!m && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1697,6 +1798,11 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
                 const double nt = s[9] > 0 ? s[9] : 1;
                 double tot = 0;
                 for (int k = 0; k < 8; ++k) tot += s[k];
+                if (mxk2)
+                    fprintf(stderr, "[attn_mx2 stamps] per generic tile per wave (s_memtime ticks), %.0f tiles: K fragments + c2p store / gather + p2c / S issue %.0f | request wait + ring barrier %.0f | "
+                                    "DMA + row requests %.0f | image stores + gathers %.0f | softmax + P.V %.0f | c2p issue %.0f | total %.0f | s_memtime clock %.0f MHz\n",
+                            nt, (s[0] + s[1]) / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, s[6] / nt, tot / nt, s[8] / (64 * 8) / 10.0);
+                else
                 fprintf(stderr, "[attn_mx stamps] per band tile per wave (s_memtime ticks), %.0f tiles: request wait %.0f | K + c2p gather + p2c/S issue %.0f | row requests %.0f | "
                                 "barrier X %.0f | image stores + barrier Y %.0f | DMA + image gather %.0f | c2p issue + softmax + P.V %.0f | c2p store %.0f | total %.0f | s_memtime clock %.0f MHz\n",
                         nt, s[0] / nt, s[1] / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, s[6] / nt, s[7] / nt, tot / nt, s[8] / (64 * 8) / 10.0);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 36 + g4 * 8 + 4);
                 const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const int m = m0 + wm * 128 + c * 32 + row;
-                gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * Iw, (n0 >> 1) + wn * 32 + g4 * 8, v, kHi, kLo);
+                gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * Iw, (n0 >> 1) + wn * 32 + g4 * 8, v, kHi, kLo, p.gx_sat);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
 #pragma unroll
                         for (int o = 1; o < 8; o <<= 1) s2 += __shfl_xor(s2, o, 64);
                         if (g8 == 0) p.ln_part[(size_t)m * (N >> 6) + ((n0 + wn * 64) >> 6)] = make_float2(s1, s2);
-                        gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo);
+                        gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, p.gx_sat);
                     } else {             // plain fp32 row (LayerNorm input)
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                         const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;
                         const int bh = b * p.nh + hh;
                         if (p.qkv_mxt) {        // MX tiles (glc_layout.h): f16 unit piece + the fp8 parts, Q as (hi8 | lo8), K as (lo8 | hi8)
+                            gx_range_note(v, kHi, p.gx_sat);
                             float lo8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) lo8[e] = (v[e] - (float)o[e]) * kLo;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo);      // FFN1's intermediate: streams (non-temporal)
+                    } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, p.gx_sat);      // FFN1's intermediate: streams (non-temporal)
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                     while (sq >= p.Sp) { sq -= p.Sp; ++b; }
                     if (p.qkv_mxt) {            // V^T MX tiles: (lo8 | hi8)
                         const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        gx_range_note(x8, kHi, p.gx_sat);
                         float r8[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) r8[e] = (x8[e] - (float)o[e]) * kLo;
@@ -523,7 +525,9 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
     return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_SWIGLU;
 }
 
-const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a) {
+const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
+    GemmArgs a = a_in;
+    if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the activation images this launch writes
     if (!glc_gemm256x_supported(a, epi)) return "gemm256x: unsupported shape";
     if (!a.A || !a.W) return "gemm256x: null operand";
     if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256x: null QKV output"; }

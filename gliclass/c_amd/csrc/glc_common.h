@@ -177,11 +177,26 @@ __device__ __forceinline__ uint32_t glc_fp8x4(float a, float b, float c, float d
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (uint32_t)w;
 }
+// fp8 range guard.  An activation beyond the e4m3 range (|x| 2^sc > 448) saturates in its fp8 parts: its cross terms — and the lo8 part a
+// residual read-back adds to hi — are then wrong by up to 2^-11 of the element, i.e. that element falls to single-f16 accuracy without any
+// error being raised.  Synthetic weights never get there; the outlier channels of trained checkpoints (10^2 .. 10^4 in the raw residual
+// stream of a pre-norm decoder) do.  Every producer of an activation operand image (GX rows, MX tiles) therefore counts such elements
+// in a per-engine device counter (sat != nullptr); the engine reads it with the logits and repeats a forward that counted any on the
+// split-f16 kernels, whose operands hold up to 65504 (engine.hip forward_one).
+__device__ __forceinline__ void gx_range_note(const float (&v)[8], float k_hi, unsigned* sat) {
+    if (!sat) return;
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+    m = fmaxf(fmaxf(m, fabsf(v[3])), fabsf(v[4]));
+    m = fmaxf(fmaxf(m, fabsf(v[5])), fabsf(v[6]));
+    m = fmaxf(m, fabsf(v[7]));
+    if (m * k_hi > 448.0f) atomicAdd(sat, 1u);
+}
 // eight consecutive elements e0 .. e0 + 7 (e0 % 8 == 0) of a GX row; `row` = the row's first byte; k_hi = 2^sc, k_lo = 2^(sc + SHIFT)
 // NT: non-temporal stores — for an output that streams to HBM and is too large for the caches to keep until its reader runs (FFN1's 805 MB
 // intermediate at c3): it then does not evict the operand panels the same launch is still re-reading (FFN1 + GELU 750 -> 717 us).
 template <bool WORDER = false, bool NT = false>
-__device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const float (&v)[8], float k_hi, float k_lo) {
+__device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const float (&v)[8], float k_hi, float k_lo, unsigned* sat = nullptr) {
+    gx_range_note(v, k_hi, sat);
     gs_h8 hi;
     float l[8];
 #pragma unroll

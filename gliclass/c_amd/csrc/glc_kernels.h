@@ -9,6 +9,10 @@ enum { GLC_DT_F32 = 0, GLC_DT_BF16 = 1, GLC_DT_F16 = 2 };  // == GLC_F32/BF16/F1
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3,
        EPI_SWIGLU = 4 };   // gemm256s only: W rows interleave 16 gate / 16 up features; C [Mpad, N/2] = silu(gate) * up
 
+// fp8 range guard (glc_common.h gx_range_note): the device counter the launchers of this host thread hand to every kernel that writes
+// activation operand images (GX rows, MX tiles).  Set by the engine around its launch sequence (under its lock); null = no counting.
+inline unsigned*& glc_gx_sat_ptr() { static thread_local unsigned* p = nullptr; return p; }
+
 struct GemmArgs {
     const void* A = nullptr;      // [Mpad, K]  T
     const void* W = nullptr;      // [N, K]     T
@@ -50,6 +54,7 @@ struct GemmArgs {
     int prio_mode = -1;                     // gemm256x: wave priority policy of the main loop (-1: default / GLC_GEMM_PRIO; developer A/B)
     int qkv_mxt = 0;                        // gemm256x, EPI_QKV: write Q / K / V^T as MX tiles (glc_layout.h) for attention_mx.hip instead of split-f16 units
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
+    unsigned* gx_sat = nullptr;             // gemm256x: fp8 range guard counter (filled by the launcher from glc_gx_sat_ptr())
 };
 // Precision-budget mask of an engine (developer, gliclass_hip.h glc_debug_set_precision_mask): a set bit rounds that operand of the
 // default mode's group-split pipeline to f16 by dropping its lo halves (numerically identical to the cheaper kernel that never
@@ -144,6 +149,8 @@ struct AttnArgs {
     int ctx_gs = 0;                                   // workgroup-shared kernel, split operands: write CTX rows in the GS format (1) or the GX format (2)
     int ksplit = 0;                                   // per-wave band kernel with tile_flag: a workgroup with ONE flagged query tile splits that tile's keys over its 4 waves
     int prec = 0;                                     // workgroup-shared kernel, split units: (engine mask >> 8) & 63 — bits Q, K, V, P, PQ, PK rounded to f16
+    const void* idx16 = nullptr; const int4* tinfo = nullptr;   // attention_mx2.hip: the tables of glc_mx2_build_tables for this Sp
+    unsigned* gx_sat = nullptr;                       // GX context rows: fp8 range guard counter (filled by the launchers from glc_gx_sat_ptr())
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel, one independent wave per 32-query tile (attention.hip)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);
@@ -154,8 +161,14 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
 // Workgroup-shared band kernel on MX tiles (attention_mx.hip; the attention of the MX pipeline): Qh / Kh / Vt / PQ / PK are MX tiles
 // (glc_layout.h), CTX is written as GX rows; otab is the split-unit offset table.
 const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a);
+// Round 4: the same operands and outputs, position terms in bucket (delta) space, one independent wave per query tile (attention_mx2.hip).
+// glc_mx2_build_tables: the kernel's two tables from the distance -> delta table of a padded length; false = this table does not have the
+// structure the kernel needs (the caller keeps glc_launch_attention_mx).
+const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a);
+#include <vector>
+bool glc_mx2_build_tables(int Sp, int P, const int32_t* dtab, std::vector<unsigned char>& idx16, std::vector<int4>& tinfo);
 // position tables at load: split-f16 units (Q / K layout, ntiles tiles of 32 rows x 64 columns) -> MX tiles; hl: (hi8 | lo8) order (PQ), else (lo8 | hi8) (PK)
-const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl);
+const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat = nullptr);   // sat: fp8 range guard counter (glc_common.h)
 
 #include <atomic>
 // CU count of the CURRENT device, cached per device ordinal (a session may span GPUs of different sizes)
@@ -193,7 +206,9 @@ const char* glc_launch_head_score(hipStream_t st, const float* Tt, const float* 
 const char* glc_launch_scorer_wd_cat(hipStream_t st, const float* St, const float* Sc, float* cat, int B, int C, int H);
 const char* glc_launch_scorer_pair(hipStream_t st, const float* Tt, const float* Cc, float* out, int B, int C, int H);
 const char* glc_launch_relu(hipStream_t st, float* x, size_t n);
-const char* glc_launch_relu_dot(hipStream_t st, const float* X, const float* w, const float* bias, float* logits, int rows, int K);
+const char* glc_launch_relu_dot(hipStream_t st, const float* X, const float* w, const float* bias, float* logits, int rows, int K, float scale = 1.0f);
+// normalize_features ahead of those scorers: X[r][:] /= (|X[r]| + 1e-8), rows x H fp32 in place
+const char* glc_launch_l2norm_rows(hipStream_t st, float* X, int rows, int H);
 
 // Pruned last layer: compact the rows the head reads. Row r < B: [CLS] of sequence r; row B + b*C + j: class
 // token j of sequence b (sequence start if absent). Writes Xs[r,:] = X[row,:] and the (sequence, position) lists.

@@ -61,8 +61,8 @@ __device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restri
 // halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
 // LayerNorm of one fp32 row by one wave, output in the GS format (8 elements per lane and chunk)
 // (GX = true: the same 128-byte groups as GX rows — [32 hi | 32 lo8 | 32 hi8], glc_common.h — for the MX cross-term GEMM; activation exponent 0)
-template <bool GX> __device__ __forceinline__ void row_store8(f16_t* y, int e0, const float (&v)[8]) {
-    if constexpr (GX) gx_store8(reinterpret_cast<unsigned char*>(y), e0, v, 1.0f, (float)(1 << GLC_GX_SHIFT));
+template <bool GX> __device__ __forceinline__ void row_store8(f16_t* y, int e0, const float (&v)[8], unsigned* sat = nullptr) {
+    if constexpr (GX) gx_store8(reinterpret_cast<unsigned char*>(y), e0, v, 1.0f, (float)(1 << GLC_GX_SHIFT), sat);      // (sat: fp8 range guard, glc_common.h)
     else gs_store8(y, e0, v);
 }
 template <bool GX> __device__ __forceinline__ void row_load8(const f16_t* y, int e0, float (&v)[8]) {
@@ -71,7 +71,7 @@ template <bool GX> __device__ __forceinline__ void row_load8(const f16_t* y, int
 }
 template <bool MASKED, bool GX = false>
 __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_t* __restrict__ y, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float eps, int H, float mk, int lane) {
+                                               const float* __restrict__ beta, float eps, int H, float mk, int lane, unsigned* sat = nullptr) {
     const int nch = H / 8;
     float v[MAXC][8];
     float s = 0.f;
@@ -105,20 +105,20 @@ __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_
                 if (MASKED) r *= mk;
                 o[e] = r;
             }
-            row_store8<GX>(y, ch * 8, o);
+            row_store8<GX>(y, ch * 8, o, sat);
         }
     }
 }
 template <bool GX>
 __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, int M, int H) {
+                                                           const float* __restrict__ beta, float eps, int M, int H, unsigned* sat) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    ln_row_wave_gs<false, GX>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63);
+    ln_row_wave_gs<false, GX>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63, sat);
 }
 // decoder backbone, RMSNorm folded into the GEMMs: the embedding rows (plain fp32) enter the pipeline as raw group-split rows + (0, rstd)
 template <bool GX>
-__global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H) {
+__global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H, unsigned* sat) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63, nch = H / 8;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __rest
         const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-        row_store8<GX>(y, ch * 8, v);
+        row_store8<GX>(y, ch * 8, v, sat);
     }
     ss = wave_sum(ss);
     if (lane == 0) stats[row] = make_float2(0.f, rsqrtf(ss / (float)H + eps));
@@ -157,7 +157,7 @@ template <bool GX>
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, f16_t* __restrict__ X,
-                                                       float* __restrict__ kbias, int B, int S, int Sp, int H, int vocab, int pad_id) {
+                                                       float* __restrict__ kbias, int B, int S, int Sp, int H, int vocab, int pad_id, unsigned* sat) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row in the padded [B, Sp] grid
     if (row >= B * Sp) return;
     const int lane = threadIdx.x & 63;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict
         if (id < 0 || id >= vocab) id = pad_id;
     }
     if (lane == 0) kbias[row] = mk != 0.f ? 0.f : GLC_NEG_BIG;
-    ln_row_wave_gs<true, GX>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane);
+    ln_row_wave_gs<true, GX>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane, sat);
 }
 // pruned last layer: rows the head reads, GS hidden states -> plain fp32 compact rows (that layer runs on the fp32-format kernels)
 template <bool GX>
@@ -401,9 +401,21 @@ __global__ __launch_bounds__(256) void scorer_pair_kernel(const float* __restric
 __global__ __launch_bounds__(256) void relu_kernel(float* __restrict__ x, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = fmaxf(x[i], 0.f);
 }
-// logits[r] = sum_k relu(X[r][k]) * w[k] + bias[0]   (ReLU -> Linear(K, 1)); one wave per row
+// X[r][:] /= (|X[r]| + 1e-8)   (normalize_features ahead of the 'weighted-dot' / 'mlp' scorers; the dot scorer normalises inside its kernel); one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ X, int rows, int H) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* x = X + (size_t)r * H;
+    float a = 0.f;
+    for (int i = lane; i < H; i += 64) a += x[i] * x[i];
+    a = wave_sum(a);
+    const float inv = 1.0f / (sqrtf(a) + 1e-8f);
+    for (int i = lane; i < H; i += 64) x[i] *= inv;
+}
+// logits[r] = (sum_k relu(X[r][k]) * w[k] + bias[0]) * scale   (ReLU -> Linear(K, 1)); one wave per row
 __global__ __launch_bounds__(256) void relu_dot_kernel(const float* __restrict__ X, const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ logits, int rows, int K) {
+                                                       float* __restrict__ logits, int rows, int K, float scale) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(256) void relu_dot_kernel(const float* __restrict__
     float a = 0.f;
     for (int i = lane; i < K; i += 64) a += fmaxf(x[i], 0.f) * w[i];
     a = wave_sum(a);
-    if (lane == 0) logits[r] = a + bias[0];
+    if (lane == 0) logits[r] = (a + bias[0]) * scale;
 }
 
 template <typename T>
@@ -461,8 +473,8 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
 const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H, int gx) {
     if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm_gs: bad args";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "layernorm_gs: unsupported hidden size";
-    if (gx) hipLaunchKernelGGL(layernorm_gs_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
-    else hipLaunchKernelGGL(layernorm_gs_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H);
+    if (gx) hipLaunchKernelGGL(layernorm_gs_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, glc_gx_sat_ptr());
+    else hipLaunchKernelGGL(layernorm_gs_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, (unsigned*)nullptr);
     return nullptr;
 }
 
@@ -474,8 +486,8 @@ const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, 
 
 const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H, int gx) {
     if (!X || !Y || !stats || M <= 0 || H <= 0 || H % 32) return "rows_to_gs_rms: bad args";
-    if (gx) hipLaunchKernelGGL(rows_to_gs_rms_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H);
-    else hipLaunchKernelGGL(rows_to_gs_rms_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H);
+    if (gx) hipLaunchKernelGGL(rows_to_gs_rms_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H, glc_gx_sat_ptr());
+    else hipLaunchKernelGGL(rows_to_gs_rms_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H, (unsigned*)nullptr);
     return nullptr;
 }
 
@@ -484,8 +496,8 @@ const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_
     if (B <= 0 || S <= 0 || Sp < S || !ids || !mask || !table || !X || !kbias) return "embed_gs: bad args";
     if (pad_id < 0 || pad_id >= vocab) return "embed_gs: pad id outside vocab";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "embed_gs: unsupported hidden size";
-    if (gx) hipLaunchKernelGGL(embed_gs_kernel<true>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id);
-    else hipLaunchKernelGGL(embed_gs_kernel<false>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id);
+    if (gx) hipLaunchKernelGGL(embed_gs_kernel<true>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id, glc_gx_sat_ptr());
+    else hipLaunchKernelGGL(embed_gs_kernel<false>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id, (unsigned*)nullptr);
     return nullptr;
 }
 
@@ -570,9 +582,14 @@ const char* glc_launch_relu(hipStream_t st, float* x, size_t n) {
     if (n) hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, x, n);
     return nullptr;
 }
-const char* glc_launch_relu_dot(hipStream_t st, const float* X, const float* w, const float* bias, float* logits, int rows, int K) {
+const char* glc_launch_relu_dot(hipStream_t st, const float* X, const float* w, const float* bias, float* logits, int rows, int K, float scale) {
     if (rows <= 0 || K <= 0 || !X || !w || !bias || !logits) return "relu_dot: bad args";
-    hipLaunchKernelGGL(relu_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, w, bias, logits, rows, K);
+    hipLaunchKernelGGL(relu_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, w, bias, logits, rows, K, scale);
+    return nullptr;
+}
+const char* glc_launch_l2norm_rows(hipStream_t st, float* X, int rows, int H) {
+    if (rows <= 0 || H <= 0 || !X) return "l2norm_rows: bad args";
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, X, rows, H);
     return nullptr;
 }
 

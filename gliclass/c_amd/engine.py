@@ -128,6 +128,22 @@ class Engine:
     def last_mx(self):
         return bool(self.L.glc_debug_last_forward_mx(self.h))
 
+    def last_mx_attention(self):
+        """the last forward's attention ran on MX tiles (attention_mx.hip)"""
+        return bool(self.L.glc_debug_last_forward_mx_attention(self.h))
+
+    def fp8_range_retries(self):
+        """host-buffer forwards repeated on the split-f16 kernels because an activation left the fp8 range of the MX operand images"""
+        return int(self.L.glc_debug_fp8_range_retries(self.h))
+
+    def fp8_range_sticky(self):
+        """the engine has left the MX pipeline for good (outlier channels in consecutive forwards)"""
+        return bool(self.L.glc_debug_fp8_range_sticky(self.h))
+
+    def set_mx2(self, on):
+        """MX attention on the bucket-space kernel (attention_mx2.hip) or on the band kernel (attention_mx.hip)"""
+        self.L.glc_debug_set_mx2(self.h, int(bool(on)))
+
     def range_retries(self):
         """host-buffer forwards repeated with the norms unfused because the folded forward came out non-finite"""
         return int(self.L.glc_debug_range_retries(self.h))

@@ -148,7 +148,9 @@ int glc_debug_last_forward_group_split(const glc_engine* e);
  * block-scaled fp8 MFMA, on "GX" rows.  Needs the GX weight copies, i.e. an engine created under GLICLASS_MX=1 (selected) or =build. */
 int glc_debug_set_mx(glc_engine* e, int on);
 int glc_debug_last_forward_mx(const glc_engine* e);
-int glc_debug_set_mx_attention(glc_engine* e, int on);     /* MX pipeline: attention on MX tiles (default) / on split-f16 units */
+int glc_debug_last_forward_mx_attention(const glc_engine* e);   /* 1: the last forward's attention ran on MX tiles (two MFMA times per product) */
+int glc_debug_set_mx_attention(glc_engine* e, int on);
+int glc_debug_set_mx2(glc_engine* e, int on);              /* MX attention: bucket-space kernel (attention_mx2.hip) / band kernel (attention_mx.hip, default) */     /* MX pipeline: attention on MX tiles (default) / on split-f16 units */
 /* Developer: stop forwards after a stage and read workspace rows decoded to fp32 (engine.hip). */
 int glc_debug_set_stop(glc_engine* e, int stage);
 int glc_debug_read_workspace(glc_engine* e, int which, int rows, float* out);
@@ -163,6 +165,10 @@ int glc_debug_set_precision_mask(glc_engine* e, int mask);
 /* Host-buffer forwards that were repeated with the norms unfused because the folded forward came out non-finite (a raw residual
  * stream beyond the f16 operand range; engine.hip forward_one). */
 int glc_debug_range_retries(const glc_engine* e);
+/* fp8 range guard of the MX pipeline: host-buffer forwards repeated on the split-f16 kernels because an activation left the e4m3 range of the
+ * operand images (|x| > 448); 1 once the engine has left the MX pipeline for good (two such forwards in a row, or one seen by glc_engine_sync) */
+int glc_debug_fp8_range_retries(const glc_engine* e);
+int glc_debug_fp8_range_sticky(const glc_engine* e);
 /* 256-tile GEMM ring: full-line (operand-major) stages on / off, process-wide developer A/B switch; bit-identical results. */
 int glc_debug_set_gemm_full_lines(int on);
 

@@ -210,7 +210,7 @@ static void glo_head(const glo_config* cfg, const float* const* hw, const float*
                 const float* hrow = hid + ((size_t)b * C + j) * 4 * H;
                 float a = 0;
                 for (int i = 0; i < 4 * H; ++i) a += (hrow[i] > 0.f ? hrow[i] : 0.f) * sw[6][i];
-                logits[(size_t)b * c_alloc + j] = a + sw[7][0];
+                logits[(size_t)b * c_alloc + j] = (a + sw[7][0]) * (cfg->normalize_features ? cfg->logit_scale : 1.0f);
             }
         free(T); free(L); free(cat); free(hid);
     } else if (cfg->scorer == 2 && C > 0) {
@@ -231,7 +231,7 @@ static void glo_head(const glo_config* cfg, const float* const* hw, const float*
         for (int r = 0; r < B * C; ++r) {
             float a = 0;
             for (int i = 0; i < Mh / 2; ++i) { const float v = h2[(size_t)r * (Mh / 2) + i]; a += (v > 0.f ? v : 0.f) * sw[4][i]; }
-            logits[(size_t)(r / C) * c_alloc + (r % C)] = a + sw[5][0];
+            logits[(size_t)(r / C) * c_alloc + (r % C)] = (a + sw[5][0]) * (cfg->normalize_features ? cfg->logit_scale : 1.0f);
         }
         free(cat); free(h1); free(h2);
     } else

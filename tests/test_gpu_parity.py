@@ -429,6 +429,19 @@ def test_scorer_switches(scorer, weights_for):
                 eng.close()
             assert got.shape == ref.shape
             assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (cname, dtype)
+    # normalize_features with these scorers: features L2-normalised before the scorer GEMMs, logits times logit_scale
+    cfg = dataclasses.replace(CONFIGS["tiny"], scorer=SCORER_NAMES[scorer], normalize_features=True, logit_scale=3.5)
+    w = weights.make_weights(cfg, 42)
+    ids, mask, _ = synth.make_inputs(cfg, 4, 150, 3, seed=17, ragged=True, labels_per_row=[3, 1, 0, 2])
+    ref = oracle_c.forward(cfg, w, ids, mask)
+    plain = oracle_c.forward(dataclasses.replace(cfg, normalize_features=False, logit_scale=1.0), w, ids, mask)
+    assert np.abs(ref - plain).max() > 1e-3, "the switch must change the logits"
+    eng = Engine(cfg, w, dtype="f32")
+    try:
+        got = eng.forward(ids, mask)
+    finally:
+        eng.close()
+    assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB["f32"]
 
 
 def test_length_bucketing_decoder_backbone(engines, weights_for):

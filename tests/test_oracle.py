@@ -61,8 +61,9 @@ def test_sigmoid_matches_reference_formula():
         assert abs(lib.glo_sigmoid(x) - 1.0 / (1.0 + np.exp(-x))) < 1e-7
 
 
+@pytest.mark.parametrize("normalize", [False, True])
 @pytest.mark.parametrize("scorer", ["weighted-dot", "mlp"])
-def test_oracle_scorer_variants_vs_torch_modules(scorer):
+def test_oracle_scorer_variants_vs_torch_modules(scorer, normalize):
     """The head's other scorers ('must be config-switchable'): the C oracle against the same modules written
     with torch.nn, on the oracle's own final hidden states.  The module structure is the upstream `gliclass` package's as restated in
     include/gliclass_hip.h (not on disk here: parity with upstream stays unpinned); this pins the oracle's arithmetic to torch's."""
@@ -71,7 +72,8 @@ def test_oracle_scorer_variants_vs_torch_modules(scorer):
     from gliclass.c_amd.config import CONFIGS, SCORER_NAMES
     from gliclass.c_amd import synth
     from gliclass.c_amd.weights import make_weights
-    cfg = dataclasses.replace(CONFIGS["tiny"], scorer=SCORER_NAMES[scorer])
+    # normalize_features: projected text / class features L2-normalised before the scorer, logits times logit_scale (every scorer)
+    cfg = dataclasses.replace(CONFIGS["tiny"], scorer=SCORER_NAMES[scorer], normalize_features=bool(normalize), logit_scale=3.5 if normalize else 1.0)
     w = make_weights(cfg, 7)
     B, S, C = 3, 48, 3
     ids, mask, _ = synth.make_inputs(cfg, B, S, C, seed=5, ragged=True)
@@ -85,6 +87,9 @@ def test_oracle_scorer_variants_vs_torch_modules(scorer):
     text = proj(X[:, 0, :], "text_projector")                                       # pooling 'first'
     pos = np.stack([np.nonzero(ids[b] == cfg.class_token_index)[0][:C] for b in range(B)])
     cls = proj(torch.stack([X[b, pos[b], :] for b in range(B)]), "classes_projector")     # [B, C, H]
+    if normalize:
+        text = text / (text.norm(dim=-1, keepdim=True) + 1e-8)
+        cls = cls / (cls.norm(dim=-1, keepdim=True) + 1e-8)
     if scorer == "weighted-dot":
         t = lin(text, "scorer.proj_text").view(B, 1, 1, 2, H)
         l = lin(cls, "scorer.proj_label").view(B, 1, C, 2, H)
@@ -95,6 +100,8 @@ def test_oracle_scorer_variants_vs_torch_modules(scorer):
     else:
         comb = torch.cat([text.unsqueeze(1).expand(-1, C, -1), cls], dim=-1)
         want = lin(torch.relu(lin(torch.relu(lin(comb, "scorer.mlp.0")), "scorer.mlp.2")), "scorer.mlp.4").squeeze(-1)
+    if normalize:
+        want = want * cfg.logit_scale
     want = want.numpy()
     assert np.abs(want).max() > 0.05 and np.abs(want).max() < 30, "synthetic scorer weights should give logits in the sigmoid's range"
     np.testing.assert_allclose(logits, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))

@@ -66,9 +66,21 @@ def kernel_flops(cfg, B, S):
     }
 
 
-def time_steps(step_fn, sync_fn, barrier_fn, max_fn, steps, warmup):
+def git_head():
+    """The commit this tree is at (None where no .git travels with it, e.g. on a gpurun box: scripts pass GLICLASS_BENCH_COMMIT there)."""
+    try:
+        head = open(os.path.join(ROOT, ".git", "HEAD")).read().strip()
+        if head.startswith("ref:"):
+            return open(os.path.join(ROOT, ".git", head[5:])).read().strip()
+        return head
+    except Exception:
+        return None
+
+
+def time_steps(step_fn, sync_fn, barrier_fn, max_fn, steps, warmup, own=None):
     """The timing contract: W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on
-    both sides; returns the max over ranks of the elapsed seconds."""
+    both sides; returns the max over ranks of the elapsed seconds.  `own` (a list) receives this rank's own
+    time to its device sync, before the closing barrier: a straggler shows in the spread of those."""
     for _ in range(warmup):
         step_fn()
     sync_fn()
@@ -78,8 +90,11 @@ def time_steps(step_fn, sync_fn, barrier_fn, max_fn, steps, warmup):
     for _ in range(steps):
         step_fn()
     sync_fn()
+    t_own = time.perf_counter()
     barrier_fn()
     t1 = time.perf_counter()
+    if own is not None:
+        own.append(t_own - t0)
     return max_fn(t1 - t0)
 
 
@@ -294,7 +309,7 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
         ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(dtype)
         if ent and ent.get("config") == config_key and dom in ent.get("kernels", {}):
             traffic = ent["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/traffic.json (" + ent.get("source", "?") + ")"
+            traffic_src = "profiles/traffic.json (" + ent.get("source", "?") + (", commit " + str(ent["commit"])[:12] if ent.get("commit") else "") + ")"
     except Exception:
         pass
     # matrix-pipe time per product in f16-MFMA units, per kernel class.  MX (projections; attention when it runs on MX tiles): a_hi*w_hi as
@@ -448,9 +463,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed = time_steps(step, runner.sync, barrier, max_over_ranks, args.steps, args.warmup)
+    own = []
+    elapsed = time_steps(step, runner.sync, barrier, max_over_ranks, args.steps, args.warmup, own)
     seqs_per_s = global_rows * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    # every rank's own time per step (to its device sync, before the closing barrier): min / max over the ranks — a straggler is visible in the line
+    own_ms = own[0] / args.steps * 1e3
+    rank_ms = {"min": round(-max_over_ranks(-own_ms), 3), "max": round(max_over_ranks(own_ms), 3)}
+    omp_threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    assert omp_threads >= 1, "host threads per rank"
 
     out = None
     if args.stub:
@@ -458,6 +479,7 @@ def main():
             full = gathered[0] if gathered[0] is not None else runner.logits
             out = {"metric": "stub", "value": round(seqs_per_s, 2), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "scaling": args.scaling, "global_batch": global_rows, "rows_rank0": B, "step_calls_rank0": runner.calls,
+                   "rank_ms_per_step": rank_ms, "omp_threads_per_rank": omp_threads,
                    "gathered_rows": [int(v) for v in (full[:, 0] / 16).tolist()] if args.scaling == "strong" else None}
     else:
         h = runner.h
@@ -518,11 +540,13 @@ def main():
                 "metric": f"sequences/sec at batch={args.batch} seq={S}, gliclass-{args.config}; %MFMA-peak",
                 "value": round(seqs_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+                "commit": os.environ.get("GLICLASS_BENCH_COMMIT") or git_head(),
                 "dtype": args.dtype, "mode": mode_txt, "mx_projections": mx_on, "mx_attention": mx_attn_on, "data": "synthetic",
                 "config": {"workload": f"{shape_txt}, batch={args.batch} seq={S} labels={Cn}, random-init weights (seed 42), full-length rows",
                            "global_batch": global_rows, "seq_len": S,
                            "parallelism": (f"batch-shard x{world}: one process per GPU, every rank a full batch, no data-path collective" if args.scaling == "weak" else
                                            f"batch-shard x{world}: one global batch split contiguously ({B} rows on rank 0), logits all-gathered to rank 0 every step (RCCL)")},
+                "rank_ms_per_step": rank_ms, "omp_threads_per_rank": omp_threads,
                 "hip_event_ms_per_step": round(ev_ms, 3),
                 "step_ms_median": round(pct(0.5), 3), "step_ms_p10": round(pct(0.1), 3), "step_ms_p90": round(pct(0.9), 3), "step_ms_samples": len(lap),
                 "finite": bool(np.isfinite(logits).all()),

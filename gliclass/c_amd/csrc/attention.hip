@@ -573,7 +573,7 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
         const int nqb = (a.Sp + 127) / 128, bh8 = (a.B * a.nh + 7) / 8 * 8;
         dim3 grid(nqb * bh8), block(256);
         const size_t dyn = (a.variant & 2) ? 60 * 1024 : 0;     // diagnostic: pad LDS so that one block fits per CU (one wave per SIMD)
-        static const bool unroll6 = getenv("GLC_ATTN_ROLLED") == nullptr;       // default: lean two-step band loop; the env picks the rolled one (A/B)
+        static const bool unroll6 = glc_dev_env("GLC_ATTN_ROLLED") == nullptr;       // default: lean two-step band loop; the env picks the rolled one (A/B)
         if (dtype == GLC_DT_F32) {
             if (a.stamps) return "attention: the stamped build exists for f16 only";
             // The lean (in-place reload) loop with split fragments: round 1 measured it 5 % faster but WRONG (err 5e-2).  Root cause (round 2,
@@ -582,8 +582,8 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
             // with -fno-slp-vectorize, which is how this translation unit is built (Makefile); in that build the instantiation passes the
             // whole fp32 parity suite (GLC_ATTN_WG=0 GLC_ATTN_SPLIT_LEAN=1).  It stays a diagnostic: the split mode's attention is
             // attention_wg.hip, and this kernel serves it only for the pruned last layer, in the rolled form.
-            static const bool lean32 = getenv("GLC_ATTN_F32_LEAN") != nullptr;      // diagnostic only: plain fp32 fragments, lean loop
-            static const bool split_lean = getenv("GLC_ATTN_SPLIT_LEAN") != nullptr;     // diagnostic only: split fragments, lean loop
+            static const bool lean32 = glc_dev_env("GLC_ATTN_F32_LEAN") != nullptr;      // diagnostic only: plain fp32 fragments, lean loop
+            static const bool split_lean = glc_dev_env("GLC_ATTN_SPLIT_LEAN") != nullptr;     // diagnostic only: split fragments, lean loop
             if (a.split && split_lean) hipLaunchKernelGGL((attn_band_kernel<float, true, false, true>), grid, block, dyn, st, a);
             else if (a.split) hipLaunchKernelGGL((attn_band_kernel<float, false, false, true>), grid, block, dyn, st, a);
             else if (lean32) hipLaunchKernelGGL((attn_band_kernel<float, true>), grid, block, dyn, st, a);

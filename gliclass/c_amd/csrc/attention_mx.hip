@@ -550,7 +550,7 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     if (a.stamps) return go(attn_mx_kernel<NW, 0, true>, r4);
     if (a.variant & 256) return go(attn_mx_kernel<NW, 1>, r1);
     if (a.variant & 512) return go(attn_mx_kernel<NW, 2>, r2);
-    static const bool pv16_env = getenv("GLC_ATTN_PV16") && atoi(getenv("GLC_ATTN_PV16")) != 0;
+    static const bool pv16_env = glc_dev_env("GLC_ATTN_PV16") && atoi(glc_dev_env("GLC_ATTN_PV16")) != 0;
     static std::atomic<unsigned> r5{0};
     if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
     return go(attn_mx_kernel<NW, 0>, r0);
@@ -564,7 +564,7 @@ const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a_in) {
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx): bad shape";
     if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
     // workgroup shape (kernel header): 4 waves x two workgroups per CU by default; GLC_ATTN_MX_NW=8 or AttnArgs::variant bit 11: 8 waves x one (bit 10: 4)
-    static const int nw_env = getenv("GLC_ATTN_MX_NW") ? atoi(getenv("GLC_ATTN_MX_NW")) : 4;
+    static const int nw_env = glc_dev_env("GLC_ATTN_MX_NW") ? atoi(glc_dev_env("GLC_ATTN_MX_NW")) : 4;
     const int nw = (a.variant & 1024) ? 4 : (a.variant & 2048) ? 8 : nw_env;
     return nw == 8 ? launch_mx<8>(st, a) : launch_mx<4>(st, a);
 }

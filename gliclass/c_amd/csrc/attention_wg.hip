@@ -577,7 +577,7 @@ template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL 
     constexpr size_t lds = wg_lds_bytes<T, SPLIT, NW, KVG, STAG, VGL>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     if (!glc_raise_lds_limit(attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD, NMM>, (int)lds, raised)) return "attention(wg): cannot raise the dynamic LDS limit";
-    static const bool dbg = getenv("GLC_ATTN_DEBUG") != nullptr;
+    static const bool dbg = glc_dev_env("GLC_ATTN_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_wg_kernel<T, SPLIT, NW, KVG, STAG, VGL, DIAG, PD, NMM>, 64 * NW, lds);
@@ -604,7 +604,7 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
         if (a.prec) return launch_wg<float, true, 8, false, false, false, false, true>(st, a);      // precision-budget build
         if (a.variant & 64) return launch_wg<float, true, 8, false, false, false, false, false, 2>(st, a);      // timing-only: two MFMAs per product
         // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
-        static const bool stag_default = getenv("GLC_ATTN_STAG") != nullptr && atoi(getenv("GLC_ATTN_STAG")) != 0;
+        static const bool stag_default = glc_dev_env("GLC_ATTN_STAG") != nullptr && atoi(glc_dev_env("GLC_ATTN_STAG")) != 0;
         if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);
         if (a.variant & 1) return launch_wg<float, true, 4, false, false, true>(st, a);      // diagnostic: 4 waves, K ring only, two workgroups per CU
         const bool stag = (a.variant & 16) ? true : ((a.variant & 32) ? false : stag_default);

@@ -78,7 +78,9 @@ struct glc_engine {
     bool w_presplit = false;        // weights of the split-f16 fp32 GEMMs are split once at load (encoder layers in fp32 mode; head projectors in every mode)
     bool dec_split = false;         // decoder backbone, fp32 mode: RoPE/layout pass writes split-f16 units, grouped-query attention on three-MFMA products
     bool attn_split = false;        // fp32 mode: band attention on split-f16 operands (three f16 MFMAs per product); GLICLASS_F32_ATTN=native turns it off
-    bool mx_built = false, mx = false;   // MX cross-term projections (gemm256x.hip) on GX rows: weights present / pipeline selected (GLICLASS_MX, glc_debug_set_mx)
+    bool mx_built = false, mx = false;   // MX cross-term projections (gemm256x.hip) on GX rows: allowed for this engine / pipeline selected (GLICLASS_MX, glc_debug_set_mx)
+    bool mx_ready = false;               // ... and the GX copies of the projection weights exist: built from the split-f16 copies by the first forward that takes the pipeline
+    size_t mx_bytes = 0;                 // their size (glc_debug_mx_weight_bytes)
     bool last_mx = false;                // the last forward ran the MX pipeline
     bool last_mx_attn = false;           // ... and its attention ran on MX tiles (attention_mx.hip)
     bool mx_attn = true;                 // MX pipeline: attention on MX tiles (attention_mx.hip); false: split-f16 units (GLC_MX_ATTN=0, glc_debug_set_mx_attention)
@@ -395,6 +397,48 @@ const char* launch_gemm128(glc_engine* e, int dt, int epi, GemmArgs a) {
     return glc_launch_gemm(e->stream, dt, epi, a);
 }
 
+// MX pipeline: the GX copies of the projection weights (hi f16 | fp8 parts, glc_common.h; each tensor with the fp8 exponent its largest
+// magnitude allows), made on the device from the split-f16 (group-split) copies by the FIRST forward that takes the pipeline — an engine
+// whose forwards never reach the 256-tile pipeline (the reference's own batches of 8 short texts) never pays their memory.
+bool build_mx_weights(glc_engine* e) {
+    if (e->mx_ready) return true;
+    unsigned* d_bits = (unsigned*)e->splitk_ws;          // (scratch: the split-K workspace is idle between launches)
+    if (!d_bits) { set_err("MX weights: no scratch"); return false; }
+    auto copy = [&](const void* gs, size_t n, void*& dst, int& ws) -> bool {
+        if (!gs) { set_err("MX weights: a split-f16 source copy is missing"); return false; }
+        unsigned bits = 0;
+        HIPCHK(hipMemsetAsync(d_bits, 0, sizeof(unsigned), e->stream), false);
+        KCHK(glc_launch_gs_absmax(e->stream, gs, n, d_bits), false);
+        HIPCHK(hipMemcpyAsync(&bits, d_bits, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), false);
+        HIPCHK(hipStreamSynchronize(e->stream), false);
+        float mxv; memcpy(&mxv, &bits, sizeof(float));
+        ws = glc_gx_weight_exponent(mxv);
+        dst = dmalloc(e, n * sizeof(float), false);
+        if (!dst) return false;
+        KCHK(glc_launch_gs_to_gx(e->stream, gs, dst, n, ws), false);
+        e->mx_bytes += n * sizeof(float);
+        return true;
+    };
+    const glc_model_config& c = e->cfg;
+    const size_t H = c.hidden, I = c.inter;
+    if (c.backbone == GLC_BACKBONE_DECODER) {
+        const size_t NQ = (size_t)c.heads * c.head_dim, NQKV = NQ + 2 * (size_t)c.kv_heads * c.head_dim;
+        for (auto& w : e->dlayers)
+            if (!copy(w.Wqkvf, NQKV * H, w.Wqkvf_x, w.ws_qkvf) || !copy(w.Wo, H * NQ, w.Wo_x, w.ws_o) ||
+                !copy(w.Wguf, 2 * I * H, w.Wguf_x, w.ws_guf) || !copy(w.Wd, H * I, w.Wd_x, w.ws_d)) return false;
+    } else {
+        for (size_t l = 0; l < e->layers.size(); ++l) {
+            LayerW& w = e->layers[l];
+            if (!copy(w.Wqkv, 3 * H * H, w.Wqkv_x, w.ws_qkv) || !copy(w.Wo, H * H, w.Wo_x, w.ws_o) || !copy(w.W2, H * I, w.W2_x, w.ws_2) ||
+                !copy(w.W1f, I * H, w.W1f_x, w.ws_1f)) return false;
+            if (l > 0 && !copy(w.Wqkvf, 3 * H * H, w.Wqkvf_x, w.ws_qkvf)) return false;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(e->stream), false);
+    e->mx_ready = true;
+    return true;
+}
+
 // The head after the row gather: the two FeaturesProjectors (Linear -> GELU -> Linear; text rows [0, rt) and class rows [rt, rt + rc)
 // share one fp32 buffer, one two-group GEMM per stage), then the scorer (include/gliclass_hip.h).
 bool run_head_tail(glc_engine* e, int B, int C, float* d_logits) {
@@ -489,10 +533,15 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     e->last_lnf = rnf;
     // MX pipeline (round 3, as the encoder's): GX rows + gemm256x for the four projections of every layer; attention stays on split units
     bool mx = rnf && e->mx && e->mx_built && e->prec_mask == 0;
+    if (mx && !build_mx_weights(e)) return false;
     for (int l = 0; mx && l < L; ++l) mx = e->dlayers[l].Wqkvf_x && e->dlayers[l].Wo_x && e->dlayers[l].Wguf_x && e->dlayers[l].Wd_x;
     e->last_mx = mx;
     e->last_mx_attn = false;
-    auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* { return mx ? glc_launch_gemm256x(st, epi, ga) : glc_launch_gemm256s_gs(st, epi, ga); };
+    auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* {
+        if (!mx) return glc_launch_gemm256s_gs(st, epi, ga);
+        GemmArgs gx = ga; gx.gx_rows = M;          // fp8 range guard: the M rows of this forward, not the slack rows up to Mpad
+        return glc_launch_gemm256x(st, epi, gx);
+    };
     if (rnf) {      // the embedding rows enter the pipeline: plain fp32 (X2) -> raw group-split rows (X) + statistics
         HIPCHK(hipMemcpyAsync(e->X2, e->X, (size_t)M * H * es, hipMemcpyDeviceToDevice, st), false);
         KCHK(glc_launch_rows_to_gs_rms(st, (const float*)e->X2, e->X, sX, c.ln_eps, M, H, mx ? 1 : 0), false);
@@ -585,7 +634,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     // fp32 mode -> 3 (1.45 vs 1.80 ms per launch: MFMA-heavy, the 3 shared p2c MFMA blocks and the shared K / V^T ring pay);
     // 16-bit operands -> 2 (0.70 vs 0.76 ms: at one MFMA per product the kernel is bound by instruction issue and latency, and
     // the workgroup barrier per tile costs more than the 3 MFMAs and 3 loads it saves).  GLC_ATTN_WG=1 / 0 forces one or the other.
-    static const int wg_env = getenv("GLC_ATTN_WG") ? atoi(getenv("GLC_ATTN_WG")) : -1;      // developer A/B switch
+    static const int wg_env = glc_dev_env("GLC_ATTN_WG") ? atoi(glc_dev_env("GLC_ATTN_WG")) : -1;      // developer A/B switch
     const bool wg_pick = wg_env >= 0 ? wg_env != 0 : dt == GLC_F32;
     int impl = e->attn_impl ? e->attn_impl : ((wg_pick && (dt != GLC_F32 || e->attn_split)) ? 3 : 2);
     if (impl == 3 && dt == GLC_F32 && !e->attn_split) impl = 2;
@@ -607,10 +656,16 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     // MX pipeline (round 3): the group-split pipeline with GX rows and the MX cross-term GEMM (gemm256x.hip) for every projection of the
     // full layers — a_hi*w_hi as f16 MFMAs, both cross terms as one block-scaled fp8 MFMA.  Needs the LayerNorm fold on every layer.
     bool mx = gs && e->mx && e->mx_built && e->ln_fused && e->prec_mask == 0 && c.layers >= 2;
+    for (int l = 0; mx && l < c.layers; ++l) mx = e->layers[l].W1f && (l == 0 || e->layers[l].Wqkvf);       // (the folded split-f16 copies the GX copies are made from)
+    if (mx && !build_mx_weights(e)) return false;
     for (int l = 0; mx && l < c.layers; ++l) mx = e->layers[l].W1f_x && e->layers[l].Wqkv_x && e->layers[l].Wo_x && e->layers[l].W2_x && (l == 0 || e->layers[l].Wqkvf_x);
     e->last_mx = mx;
     e->last_mx_attn = false;
-    auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* { return mx ? glc_launch_gemm256x(st, epi, ga) : glc_launch_gemm256s_gs(st, epi, ga); };
+    auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* {
+        if (!mx) return glc_launch_gemm256s_gs(st, epi, ga);
+        GemmArgs gx = ga; gx.gx_rows = M;          // fp8 range guard: the M rows of this forward, not the slack rows up to Mpad
+        return glc_launch_gemm256x(st, epi, gx);
+    };
     // 16-bit modes: the same LayerNorm fold on plain rows of T, when all four projections of a layer run on the staggered 256-tile kernel
     bool fold16 = false;
     if (dt != GLC_F32 && e->ln_fused && prune && !e->keep_hidden && e->attn_impl != 1 && H % 256 == 0 && I % 256 == 0 && e->statsA && e->statsB && e->ln_part) {
@@ -646,7 +701,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         if (e->debug_stop == 10 * l + 0) return true;
         AttnArgs a{e->Qh, e->Kh, e->Vt, asplit ? w.PKs : w.PK, asplit ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
         a.split = asplit; a.ctx_gs = mx ? 2 : (gs ? 1 : 0); a.prec = (pm >> 8) & 63;
-        static const bool nosat = getenv("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
+        static const bool nosat = glc_dev_env("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
         a.otab = e->otabs[Sp];
         if (mxa) { a.PK = w.PKm; a.PQ = w.PQm; e->last_mx_attn = true; a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second; }
@@ -713,7 +768,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
             a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.tile_flag = e->tile_flag; a.otab = e->otabs[Sp]; a.split = asplit;
             // selected query tiles only: the per-wave kernel skips every other tile; a workgroup of the shared kernel would run all
             // its waves for the one tile that holds the [CLS] / class-token rows
-            static const bool ksplit_on = !(getenv("GLC_ATTN_KSPLIT") && atoi(getenv("GLC_ATTN_KSPLIT")) == 0);     // developer A/B switch
+            static const bool ksplit_on = !(glc_dev_env("GLC_ATTN_KSPLIT") && atoi(glc_dev_env("GLC_ATTN_KSPLIT")) == 0);     // developer A/B switch
             a.ksplit = ksplit_on ? 1 : 0;       // a workgroup with one selected query tile splits that tile's keys over its four waves
             KCHK(e->attn_impl == 3 ? launch_band(a) : glc_launch_attention(st, dt, 2, a), false);
             KCHK(glc_launch_gather_sel(st, dt, e->CTX, e->sel_b, e->sel_q, e->CTXs, R, Sp, H), false);
@@ -776,7 +831,7 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
         // SwiGLU in the epilogue of the staggered 256-tile GEMM when the shapes allow it (16-bit operands)
         // (fp32 mode: the group-split 256-tile GEMM has the same epilogue; its small-forward fallback un-fuses on the interleaved columns)
         e->fused_swiglu = (e->dtype != GLC_F32 || (e->w_presplit && e->dec_split && H % 256 == 0)) && (2 * I) % 256 == 0 && H % 32 == 0 && I % 16 == 0 &&
-                          getenv("GLC_NO_FUSED_SWIGLU") == nullptr;
+                          glc_dev_env("GLC_NO_FUSED_SWIGLU") == nullptr;
         std::vector<float> bqkv(NQKV), gu_host(e->fused_swiglu ? 2 * (size_t)I * H : 0), fold_host;
         bool lok = true;
         for (int l = 0; l < L && lok; ++l) {
@@ -825,21 +880,6 @@ bool create_decoder(glc_engine* e, const float* const* tensors) {
                 if (!w.Wguf || !upload_as(e, wf.data(), 2 * (size_t)I * H, w.Wguf, staging)) { lok = false; break; }
                 pm = glc_launch_presplit(e->stream, w.Wguf, 2 * (size_t)I * H);
                 if (pm) { set_err(pm); lok = false; break; }
-                if (e->mx_built) {      // MX pipeline: the four projections once more as GX rows (fold_host still holds Wgu diag(ln2), interleaved)
-                    auto to_gx = [&](const float* src, size_t n, void*& dst, int& ws) -> bool {
-                        float mxv = 0.f;
-                        for (size_t i = 0; i < n; ++i) { const float a = fabsf(src[i]); mxv = a > mxv ? a : mxv; }
-                        ws = glc_gx_weight_exponent(mxv);
-                        dst = dmalloc(e, n * sizeof(float), false);
-                        if (!dst || !upload_as(e, src, n, dst, staging)) return false;
-                        const char* gm = glc_launch_to_gx(e->stream, dst, n, ws, 1);
-                        if (gm) { set_err(gm); return false; }
-                        return hipStreamSynchronize(e->stream) == hipSuccess;
-                    };
-                    if (!to_gx(wf.data(), 2 * (size_t)I * H, w.Wguf_x, w.ws_guf)) { lok = false; break; }
-                    fold_rows(t[1], NQ, t[0], wf.data()); fold_rows(t[3], NKV, t[0], wf.data() + NQ * H); fold_rows(t[5], NKV, t[0], wf.data() + (NQ + NKV) * H);
-                    if (!to_gx(wf.data(), NQKV * H, w.Wqkvf_x, w.ws_qkvf) || !to_gx(t[7], (size_t)H * NQ, w.Wo_x, w.ws_o) || !to_gx(t[11], (size_t)H * I, w.Wd_x, w.ws_d)) { lok = false; break; }
-                }
             }
             for (size_t i = 0; i < NQ; ++i) bqkv[i] = t[2][i];
             for (size_t i = 0; i < NKV; ++i) { bqkv[NQ + i] = t[4][i]; bqkv[NQ + NKV + i] = t[6][i]; }
@@ -939,7 +979,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* gv = getenv("GLICLASS_F32_GEMM"); e->w_presplit = !(gv && !strcmp(gv, "native")) ; }   // hidden and inter are multiples of 128 (checked above)
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
-    if (const char* lv = getenv("GLC_LNF")) e->ln_fused = atoi(lv) != 0;      // developer A/B switch
+    if (const char* lv = glc_dev_env("GLC_LNF")) e->ln_fused = atoi(lv) != 0;      // developer A/B switch
     // MX cross-term pipeline — the default arithmetic of the large forwards of the default mode since round 3: the
     // projections of the full layers run a_hi*w_hi in f16 MFMAs and both cross terms in one block-scaled fp8 MFMA (per-label
     // probabilities within 1e-4 of the split-f16 arithmetic, measured; the bar is 1e-3).  GLICLASS_MX=0: split-f16 projections
@@ -950,10 +990,10 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                                   : (dtype == GLC_F32 && e->w_presplit && e->attn_split && e->ln_fused && cfg->hidden % 256 == 0 && cfg->inter % 256 == 0 && cfg->layers >= 2);
         e->mx_built = eligible && !(mv && !strcmp(mv, "0"));
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
-        if (const char* av = getenv("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
-        if (const char* av = getenv("GLC_ATTN_MX2")) e->mx2 = atoi(av) != 0;         // developer A/B switch: 1 = the bucket-space kernel (attention_mx2.hip)
+        if (const char* av = glc_dev_env("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
+        if (const char* av = glc_dev_env("GLC_ATTN_MX2")) e->mx2 = atoi(av) != 0;         // developer A/B switch: 1 = the bucket-space kernel (attention_mx2.hip)
     }
-    if (const char* gv = getenv("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
+    if (const char* gv = glc_dev_env("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
     if (const char* bv = getenv("GLICLASS_LENGTH_BUCKETS")) { const int g = atoi(bv); e->max_buckets = g < 1 ? 1 : (g > 64 ? 64 : g); }
     if (dec) {
         if (!create_decoder(e, tensors)) { glc_engine_destroy(e); return nullptr; }
@@ -1083,32 +1123,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // host vectors are reused
             }
             if (lok && e->mx_built) {
-                // MX pipeline: the projection weights once more as GX rows (hi f16 | lo8 | hi8, glc_common.h), each tensor with the fp8
-                // exponent its largest magnitude allows.  (The folded copies are re-derived here: the fold above has reused its host buffer.)
-                auto to_gx = [&](const float* src, size_t n, void*& dst, int& ws) -> bool {
-                    float mx = 0.f;
-                    for (size_t i = 0; i < n; ++i) { const float a = fabsf(src[i]); mx = a > mx ? a : mx; }
-                    ws = glc_gx_weight_exponent(mx);
-                    dst = dmalloc(e, n * sizeof(float), false);
-                    if (!dst || !upload_as(e, src, n, dst, staging)) return false;
-                    const char* pm = glc_launch_to_gx(e->stream, dst, n, ws, 1);
-                    if (pm) { set_err(pm); return false; }
-                    return hipStreamSynchronize(e->stream) == hipSuccess;
-                };
-                std::vector<float> xh((size_t)(I > 3 * H ? I : 3 * H) * H);
-                const size_t HH = (size_t)H * H;
-                memcpy(xh.data(), wq.data(), HH * sizeof(float)); memcpy(xh.data() + HH, t[2], HH * sizeof(float)); memcpy(xh.data() + 2 * HH, t[4], HH * sizeof(float));
-                lok = to_gx(xh.data(), 3 * HH, w.Wqkv_x, w.ws_qkv) && to_gx(t[6], HH, w.Wo_x, w.ws_o) && to_gx(t[12], (size_t)H * I, w.W2_x, w.ws_2);
-                if (lok) {
-                    for (int n = 0; n < I; ++n) for (int k = 0; k < H; ++k) xh[(size_t)n * H + k] = t[10][(size_t)n * H + k] * t[8][k];
-                    lok = to_gx(xh.data(), (size_t)I * H, w.W1f_x, w.ws_1f);
-                }
-                if (lok && l > 0) {
-                    const float* const* tp = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * (l - 1);
-                    const float* src3[3] = {wq.data(), t[2], t[4]};
-                    for (int q = 0; q < 3; ++q) for (size_t n = 0; n < (size_t)H; ++n) for (int k = 0; k < H; ++k) xh[(q * (size_t)H + n) * H + k] = src3[q][n * H + k] * tp[14][k];
-                    lok = to_gx(xh.data(), 3 * HH, w.Wqkvf_x, w.ws_qkvf);
-                }
+                // MX pipeline: the GX copies of the projection weights are built by the first forward that takes the pipeline (build_mx_weights);
+                // the position tables are converted here (small, and the range guard decides per layer at load)
                 if (lok && w.PKs && w.PQs) {      // the position tables as MX tiles: PQ travels as (hi8 | lo8), PK as (lo8 | hi8)
                     w.PKm = dmalloc(e, (size_t)nh * P * 64 * es);
                     w.PQm = dmalloc(e, (size_t)nh * P * 64 * es);
@@ -1343,6 +1359,7 @@ int glc_debug_last_forward_groups(const glc_engine* e) { return e ? e->last_grou
 int glc_debug_range_retries(const glc_engine* e) { return e ? e->range_retries : -1; }
 int glc_debug_fp8_range_retries(const glc_engine* e) { return e ? e->fp8_retries : -1; }
 int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_off ? 1 : 0) : -1; }
+long long glc_debug_mx_weight_bytes(const glc_engine* e) { return e ? (long long)e->mx_bytes : -1; }
 int glc_debug_set_mx2(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx2 = on != 0; return 0; }
 
 int glc_engine_set_length_buckets(glc_engine* e, int max_groups) {
@@ -1450,7 +1467,7 @@ int glc_debug_last_forward_group_split(const glc_engine* e) { return e ? (e->las
 /* MX cross-term pipeline on / off (needs the GX weight copies: an engine created under GLICLASS_MX=1 or =build). */
 int glc_debug_set_mx(glc_engine* e, int on) {
     if (!e) return -1;
-    if (on && !e->mx_built) { set_err("set_mx: this engine was created without the GX weight copies (GLICLASS_MX=1 or =build)"); return -1; }
+    if (on && !e->mx_built) { set_err("set_mx: the MX pipeline is not available to this engine (shapes, dtype, or GLICLASS_MX=0 at creation)"); return -1; }
     std::lock_guard<std::mutex> lk(e->mu);
     e->mx = on != 0;
     if (on) { e->fp8_sticky_off = false; e->fp8_streak = 0; }      // (a developer switching MX back on also clears the range guard's verdict)

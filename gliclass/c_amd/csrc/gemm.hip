@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int kspl
 // Split-K pays when the 128x128 tiles alone leave most CUs idle and the K loop is long: the reference's own batches of 8 short
 // texts give M = B*Sp of ~1 k rows, i.e. 48 tiles for N = 768.  Returns the number of K parts (1 = no split).
 int splitk_parts(int epi, const GemmArgs& a, int nk) {
-    static const int mode = getenv("GLC_GEMM_SPLITK") ? atoi(getenv("GLC_GEMM_SPLITK")) : 1;        // developer A/B switch (0 = off)
+    static const int mode = glc_dev_env("GLC_GEMM_SPLITK") ? atoi(glc_dev_env("GLC_GEMM_SPLITK")) : 1;        // developer A/B switch (0 = off)
     if (!mode || epi == EPI_QKV || !a.ws || nk < 8) return 1;
     const int ncu = glc_device_cus();
     const long long tiles = (long long)(a.N / BN) * (a.Mpad / BM);

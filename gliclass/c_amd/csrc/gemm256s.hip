@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
 static std::atomic<int> g_full_lines{-1};
 static bool use_full_lines() {
     int v = g_full_lines.load(std::memory_order_relaxed);
-    if (v < 0) { v = (getenv("GLC_GEMM_FL") == nullptr || atoi(getenv("GLC_GEMM_FL")) != 0) ? 1 : 0; g_full_lines.store(v, std::memory_order_relaxed); }
+    if (v < 0) { v = (glc_dev_env("GLC_GEMM_FL") == nullptr || atoi(glc_dev_env("GLC_GEMM_FL")) != 0) ? 1 : 0; g_full_lines.store(v, std::memory_order_relaxed); }
     return v != 0;
 }
 template <typename T, int EPI, bool VMODE, bool GS = false, bool PD = false, bool FL = false, bool DIAG = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
@@ -701,7 +701,7 @@ template <typename T, int EPI, bool VMODE, bool GS = false, bool PD = false, boo
     if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS, PD, FL, DIAG>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
     GemmArgs b = a;
-    static const int ng_env = getenv("GLC_GEMM_NGROUP") ? atoi(getenv("GLC_GEMM_NGROUP")) : -1;      // developer A/B switch: 0 = row-major tile order
+    static const int ng_env = glc_dev_env("GLC_GEMM_NGROUP") ? atoi(glc_dev_env("GLC_GEMM_NGROUP")) : -1;      // developer A/B switch: 0 = row-major tile order
     b.n_group = 0;
     if (ng_env != 0 && ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);     // (6 N-tiles in 2 groups measured MORE fetch: A twice, W fitted anyway)
     hipLaunchKernelGGL((gemm256s_kernel<T, EPI, VMODE, GS, PD, FL, DIAG>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
@@ -775,7 +775,7 @@ const char* glc_launch_gemm256s(hipStream_t st, int dtype, int epi, const GemmAr
 void glc_gemm_set_full_lines(int on) { g_full_lines.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool glc_gemm_small_m(const GemmArgs& a) {
-    static const int mode = getenv("GLC_GEMM_SMALL_M") ? atoi(getenv("GLC_GEMM_SMALL_M")) : 1;     // developer A/B switch (0 = off)
+    static const int mode = glc_dev_env("GLC_GEMM_SMALL_M") ? atoi(glc_dev_env("GLC_GEMM_SMALL_M")) : 1;     // developer A/B switch (0 = off)
     if (!mode) return false;
     const int ncu = glc_device_cus();
     return (long long)(a.Mpad / TM) * (a.N / TN) * 2 < ncu;

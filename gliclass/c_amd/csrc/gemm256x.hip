@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * 36 + g4 * 8 + 4);
                 const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 const int m = m0 + wm * 128 + c * 32 + row;
-                gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * Iw, (n0 >> 1) + wn * 32 + g4 * 8, v, kHi, kLo, p.gx_sat);
+                gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * Iw, (n0 >> 1) + wn * 32 + g4 * 8, v, kHi, kLo, m < p.gx_rows ? p.gx_sat : nullptr);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
 #pragma unroll
                         for (int o = 1; o < 8; o <<= 1) s2 += __shfl_xor(s2, o, 64);
                         if (g8 == 0) p.ln_part[(size_t)m * (N >> 6) + ((n0 + wn * 64) >> 6)] = make_float2(s1, s2);
-                        gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, p.gx_sat);
+                        gx_store8(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, m < p.gx_rows ? p.gx_sat : nullptr);
                     } else {             // plain fp32 row (LayerNorm input)
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, p.gx_sat);      // FFN1's intermediate: streams (non-temporal)
+                    } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, m < p.gx_rows ? p.gx_sat : nullptr);      // FFN1's intermediate: streams (non-temporal)
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -493,7 +493,7 @@ template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0> const char* launc
     const int grid = (a.Mpad / TM) * ntn;
     GemmArgs b = a;
     b.n_group = 0;
-    static const int prio_env = getenv("GLC_GEMM_PRIO") ? atoi(getenv("GLC_GEMM_PRIO")) : 1;      // developer A/B switch
+    static const int prio_env = glc_dev_env("GLC_GEMM_PRIO") ? atoi(glc_dev_env("GLC_GEMM_PRIO")) : 1;      // developer A/B switch
     b.prio_mode = a.prio_mode >= 0 ? a.prio_mode : prio_env;
     if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);      // wide N: as gemm256s.hip
     hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE, DIAG, ABL>), dim3(grid), dim3(512), NSLOT * STAGE, st, b, n_tile0, ntn);
@@ -516,7 +516,54 @@ __global__ __launch_bounds__(256) void to_gx_kernel(float* __restrict__ w, size_
     }
 }
 
+// group-split rows ([32 hi | 32 lo] f16 halves per 32 values) -> the largest |hi + lo| (as float bits: non-negative floats order like integers)
+__global__ __launch_bounds__(256) void gs_absmax_kernel(const f16_t* __restrict__ gs, size_t ngroups, unsigned* __restrict__ out) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (gi < ngroups) {
+        const gs_h8* p = reinterpret_cast<const gs_h8*>(gs + gi * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const gs_h8 hi = p[i], lo = p[4 + i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)hi[e] + (float)lo[e]));
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+// group-split rows -> GX rows (weight order, fp8 exponent sc): the MX copies of the projection weights from their split-f16 copies on the device
+__global__ __launch_bounds__(256) void gs_to_gx_kernel(const f16_t* __restrict__ gs, unsigned char* __restrict__ gx, size_t ngroups, float k_hi, float k_lo) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const gs_h8* p = reinterpret_cast<const gs_h8*>(gs + gi * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const gs_h8 hi = p[i], lo = p[4 + i];
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)hi[e] + (float)lo[e];
+        gx_store8<true>(gx + gi * 128, 8 * i, x, k_hi, k_lo);
+    }
+}
+
 }  // namespace
+
+// n values (n % 32 == 0) as group-split rows: *d_bits (zeroed by the caller) = float bits of the largest magnitude
+const char* glc_launch_gs_absmax(hipStream_t st, const void* gs, size_t n, unsigned* d_bits) {
+    if (!gs || !d_bits || n % 32) return "gs_absmax: bad args";
+    const size_t groups = n / 32;
+    if (groups) hipLaunchKernelGGL(gs_absmax_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (const f16_t*)gs, groups, d_bits);
+    return nullptr;
+}
+// ... -> GX rows in weight order with fp8 exponent sc (what glc_launch_to_gx(.., sc, 1) makes of the fp32 values)
+const char* glc_launch_gs_to_gx(hipStream_t st, const void* gs, void* gx, size_t n, int sc) {
+    if (!gs || !gx || n % 32) return "gs_to_gx: bad args";
+    if (sc < -40 || sc > 60) return "gs_to_gx: exponent out of range";
+    const size_t groups = n / 32;
+    if (groups) hipLaunchKernelGGL(gs_to_gx_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (const f16_t*)gs, (unsigned char*)gx, groups, ldexpf(1.0f, sc), ldexpf(1.0f, sc + GLC_GX_SHIFT));
+    return nullptr;
+}
 
 bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
     if (!(a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 32 == 0)) return false;
@@ -528,6 +575,7 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
     GemmArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the activation images this launch writes
+    if (a.gx_rows <= 0) a.gx_rows = a.Mvalid > 0 ? a.Mvalid : a.Mpad;     // ... over the rows that exist (slack rows up to Mpad hold leftovers)
     if (!glc_gemm256x_supported(a, epi)) return "gemm256x: unsupported shape";
     if (!a.A || !a.W) return "gemm256x: null operand";
     if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256x: null QKV output"; }

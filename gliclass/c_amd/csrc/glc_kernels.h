@@ -9,6 +9,18 @@ enum { GLC_DT_F32 = 0, GLC_DT_BF16 = 1, GLC_DT_F16 = 2 };  // == GLC_F32/BF16/F1
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3,
        EPI_SWIGLU = 4 };   // gemm256s only: W rows interleave 16 gate / 16 up features; C [Mpad, N/2] = silu(gate) * up
 
+// Developer A/B switches (GLC_* environment variables: kernel variants kept for same-box comparisons) are read only by a
+// library built with -DGLC_DEVELOPER (make DEV=1); the product library reads the documented GLICLASS_* knobs and nothing else.
+#include <stdlib.h>
+inline const char* glc_dev_env(const char* name) {
+#ifdef GLC_DEVELOPER
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // fp8 range guard (glc_common.h gx_range_note): the device counter the launchers of this host thread hand to every kernel that writes
 // activation operand images (GX rows, MX tiles).  Set by the engine around its launch sequence (under its lock); null = no counting.
 inline unsigned*& glc_gx_sat_ptr() { static thread_local unsigned* p = nullptr; return p; }
@@ -55,6 +67,7 @@ struct GemmArgs {
     int qkv_mxt = 0;                        // gemm256x, EPI_QKV: write Q / K / V^T as MX tiles (glc_layout.h) for attention_mx.hip instead of split-f16 units
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
     unsigned* gx_sat = nullptr;             // gemm256x: fp8 range guard counter (filled by the launcher from glc_gx_sat_ptr())
+    int gx_rows = 0;                        // ... counted over rows [0, gx_rows) only: the slack rows up to Mpad hold leftovers of other forwards (0: Mvalid, else Mpad)
 };
 // Precision-budget mask of an engine (developer, gliclass_hip.h glc_debug_set_precision_mask): a set bit rounds that operand of the
 // default mode's group-split pipeline to f16 by dropping its lo halves (numerically identical to the cheaper kernel that never
@@ -102,6 +115,9 @@ bool glc_gemm256s_gs_supported(const GemmArgs& a, int epi);
 bool glc_gemm256x_supported(const GemmArgs& a, int epi);
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a);
 const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc, int worder);       // in place: n fp32 values -> GX rows, fp8 exponent sc; worder: weight rows
+// the MX weight copies from the split-f16 (group-split) copies already on the device: largest magnitude (float bits, atomicMax into *d_bits), then the conversion
+const char* glc_launch_gs_absmax(hipStream_t st, const void* gs, size_t n, unsigned* d_bits);
+const char* glc_launch_gs_to_gx(hipStream_t st, const void* gs, void* gx, size_t n, int sc);
 #ifndef GLC_GX_SHIFT
 #define GLC_GX_SHIFT 11                     // GX rows: lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)) (glc_common.h)
 #endif

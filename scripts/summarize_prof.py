@@ -60,7 +60,7 @@ dtype = sys.argv[2] if len(sys.argv) > 2 else "f16"
 config = sys.argv[3] if len(sys.argv) > 3 else "base:64:1024"
 if dtype == "f32":      # default mode: split-f16 attention (workgroup-shared kernel) and group-split GEMMs (gemm256s GS = last template flag 1)
     # (round 3: the MX cross-term GEMM gemm256x_kernel<EPI, VMODE, ...> where the MX pipeline runs, else gemm256s GS)
-    cls = {"attention": r"attn_wg_kernel(IfLb1|<float, true)", "gemm_ffn1_gelu": r"gemm256x_kernel(ILi1ELb0|<1, false)|gemm256s_kernelIDF16_Li1ELb0ELb1|gemm256s_kernel<_Float16, 1, false, true",
+    cls = {"attention": r"attn_mx2?_kernel|attn_wg_kernel(IfLb1|<float, true)", "gemm_ffn1_gelu": r"gemm256x_kernel(ILi1ELb0|<1, false)|gemm256s_kernelIDF16_Li1ELb0ELb1|gemm256s_kernel<_Float16, 1, false, true",
            "gemm_qkv": r"gemm256x_kernel(ILi3ELb0|<3, false)|gemm256s_kernelIDF16_Li3ELb0ELb1|gemm256s_kernel<_Float16, 3, false, true",
            "gemm_ffn2": r"gemm256x_kernel(ILi2ELb0|<2, false)|gemm256s_kernelIDF16_Li2ELb0ELb1|gemm256s_kernel<_Float16, 2, false, true"}
 else:
@@ -71,6 +71,8 @@ for c, pat in cls.items():
     for name, v in traffic.items():
         if re.search(pat, name) and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
             outj[c] = dict(kernel=name, hbm_bytes_per_launch=v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], **v)
-json.dump({dtype: dict(config=config, source=os.path.basename(out.rstrip("/")),
+commit = sys.argv[4] if len(sys.argv) > 4 else None
+print("commit", commit)
+json.dump({dtype: dict(config=config, source=os.path.basename(out.rstrip("/")), commit=commit,
                        note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH x2 (gfx950)", kernels=outj)},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -139,3 +139,16 @@ def test_bench_c4_alias_is_the_strong_batch_shard():
     out = _run_bench_stub("--gpus", "2", "--config", "c4", "--labels", "2", "--steps", "2", "--warmup", "1")
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["global_batch"] == 256 and out["rows_rank0"] == 128
     assert out["gathered_rows"] == list(range(256))
+
+
+def test_bench_eight_ranks_c4_shard_rehearsal():
+    """The driver's 8-GPU run, rehearsed on the CPU: `bench.py --gpus 8 --config c4` starts 8 ranks itself, joins them
+    (gloo here, RCCL there), gives each its 32 contiguous rows of the global batch of 256 and gathers the logits in order on rank 0 every
+    step; the line carries every rank's own step time (min / max: a straggler is visible) and the host threads each rank was given —
+    at least one even when the CPU quota is smaller than the rank count."""
+    out = _run_bench_stub("--gpus", "8", "--config", "c4", "--labels", "2", "--steps", "3", "--warmup", "1")
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["global_batch"] == 256 and out["rows_rank0"] == 32
+    assert out["gathered_rows"] == list(range(256))
+    assert out["step_calls_rank0"] == 4
+    assert out["omp_threads_per_rank"] >= 1
+    assert 0 < out["rank_ms_per_step"]["min"] <= out["rank_ms_per_step"]["max"]

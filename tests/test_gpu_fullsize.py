@@ -113,6 +113,9 @@ def test_c3_base_b64_s1024(dtype, c_generated_weights):
             assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX    # all 512 probabilities, mode against mode
             print(f"c3 f32, GLICLASS_MX=0: {e2:.2e}; MX vs split over all 512 probabilities {np.abs(sig(got) - sig(exact)).max():.2e}")
             eng.set_mx(True)
+            # the WHOLE batch against the oracle once (all 64 rows = 512 probabilities; ~1 minute of host cores)
+            e_all = _check_rows_vs_oracle(cfg, w, ids, mask, got, list(range(B)), TOL_MX)
+            print(f"c3 f32: all {B} rows vs the oracle: max |prob - oracle| = {e_all:.2e} (asserted {TOL_MX}, bar {BAR})")
         # row independence across the batch: the upper half alone (M = 32 768: other tile counts, same rows)
         half = eng.forward(ids[32:], mask[32:])
         assert np.abs(sig(half) - sig(got[32:])).max() <= (1e-5 if dtype == "f32" else 5e-3)

@@ -48,7 +48,8 @@ def test_mx_pipeline_odd_batch_shapes():
     sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
     try:
         eng.set_length_buckets(1)
-        for (B, S, Cn, ragged) in ((300, 192, 3, True), (100, 320, 8, True), (33, 1000, 5, True), (70, 448, 1, False), (17, 2048, 8, True), (1024, 64, 1, False)):
+        # (64, 320, ragged) is the worst shape the round-3 soak found (2.1e-4, scripts/soak_mx.py)
+        for (B, S, Cn, ragged) in ((300, 192, 3, True), (100, 320, 8, True), (64, 320, 8, True), (33, 1000, 5, True), (70, 448, 1, False), (17, 2048, 8, True), (1024, 64, 1, False)):
             ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=B + S, ragged=ragged)
             got = eng.forward(ids, mask)
             assert eng.last_mx() and np.isfinite(got).all(), (B, S)

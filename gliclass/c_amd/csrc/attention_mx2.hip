@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx2_kernel(AttnArgs a) {
     };
     // tile info (host table, glc_mx2_build_tables): x = first table row of the p2c window, y = its 32-row blocks (1: x = delta_min & ~3; 2: x = the
     // aligned block z), z = lowest aligned c2p block, w = bit 0: the window also touches block z + 1; bits 8..: its last table row
-    auto tinfo = [&](int kt) -> int4 { return a.tinfo[__builtin_amdgcn_readfirstlane(qt - kt + nt)]; };
+    auto tinfo = [&](int kt) -> int4 { int4 t = a.tinfo[__builtin_amdgcn_readfirstlane(qt - kt + nt)]; if constexpr ((ABL & 32) != 0) t.y = 1; return t; };      // (ABL 32: every window one block — timing only)
     // packed gather indices of this lane for key tile kt: byte i = 4 * (delta(q - k_i) & 63)
     const unsigned idx_lane = (unsigned)(c - 8 * h + Sp) * 16u;
     auto load_idx = [&](int kt) -> i32x4 { return *reinterpret_cast<const i32x4*>(IDXg + ((ptrdiff_t)512 * (qt - kt) + (ptrdiff_t)idx_lane)); };
@@ -587,5 +587,7 @@ const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a_in) {
     if (abl == 8) return go(attn_mx2_kernel<false, 11>, r6);
     if (abl == 16) return go(attn_mx2_kernel<false, 19>, r7);
     if (abl == 31) return go(attn_mx2_kernel<false, 31>, r8);
+    static std::atomic<unsigned> r9{0};
+    if (abl == 30) return go(attn_mx2_kernel<false, 32>, r9);
     return go(attn_mx2_kernel<false>, r0);
 }

@@ -536,7 +536,8 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     if (mx && !build_mx_weights(e)) return false;
     for (int l = 0; mx && l < L; ++l) mx = e->dlayers[l].Wqkvf_x && e->dlayers[l].Wo_x && e->dlayers[l].Wguf_x && e->dlayers[l].Wd_x;
     e->last_mx = mx;
-    e->last_mx_attn = false;
+    const bool mxa = mx && mfma && e->mx_attn;      // round 4: the attention of the MX pipeline on MX tiles too (decoder_mx.hip)
+    e->last_mx_attn = mxa;
     auto gemm_gs = [&](int epi, const GemmArgs& ga) -> const char* {
         if (!mx) return glc_launch_gemm256s_gs(st, epi, ga);
         GemmArgs gx = ga; gx.gx_rows = M;          // fp8 range guard: the M rows of this forward, not the slack rows up to Mpad
@@ -555,10 +556,12 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         if (rnf) { g.A = X; g.W = w.Wqkvf; g.a_stats = sX; }
         if (mx) { g.W = w.Wqkvf_x; g.mx_ws = w.ws_qkvf; }
         { Prof p(e, PC_QKV); KCHK(gs ? gemm_gs(EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
-          if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
+          if (mxa) KCHK(glc_launch_qkv_layout_mx(st, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);     // Q2:211 RoPE, MX tiles (decoder_mx.hip)
+          else if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
           else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
         { Prof p(e, PC_ATTN);
-          if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal, mx ? 2 : (gs ? 1 : 0)), false);
+          if (mxa) KCHK(glc_launch_attention_gqa_mx(st, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal), false);
+          else if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal, mx ? 2 : (gs ? 1 : 0)), false);
           else KCHK(glc_launch_attention_gqa(st, dt, 1, e->QKV, e->kbias, e->klen, e->CTX, B, Sp, nq, nkv, d, c.causal), false); }
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = nullptr; o.C = Xn; o.resid = X; o.Mpad = Mpad; o.N = H; o.K = NQ; o.gs_resid_plain = 1;

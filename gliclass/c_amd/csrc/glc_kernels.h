@@ -259,6 +259,12 @@ const char* glc_launch_qkv_layout(hipStream_t st, int dtype, const void* QKV, co
 const char* glc_launch_attention_gqa_mfma(hipStream_t st, int dtype, const void* Qf, const void* Kf, const void* Vt, const float* kbias,
                                           const int* klen, const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal, int ctx_gs = 0);
 
+// MX pipeline (decoder_mx.hip, round 4): the fused fp32 projection -> RoPE + scale + MX tiles (f16 hi units + fp8 steps, 4 bytes per element),
+// and the grouped-query attention on them (a_hi*b_hi in f16 MFMAs + both cross terms in one block-scaled fp8 MFMA); CTX as GX rows
+const char* glc_launch_qkv_layout_mx(hipStream_t st, const void* QKV, const float* cs, void* Qm, void* Km, void* Vm, int B, int Sp, int nq, int nkv, int d, float qscale);
+const char* glc_launch_attention_gqa_mx(hipStream_t st, const void* Qm, const void* Km, const void* Vm, const float* kbias, const int* klen, const int* kfirst, void* CTX,
+                                        int B, int Sp, int nq, int nkv, int d, int causal);
+
 // dtype conversion fp32 -> T (weights upload), n elements
 const char* glc_launch_convert(hipStream_t st, int dtype, const float* src, void* dst, size_t n);
 // In place: every group of 32 consecutive floats becomes [32 hi halves | 32 lo halves] (x = hi + lo), the LDS row image of the

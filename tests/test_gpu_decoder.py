@@ -329,3 +329,42 @@ def test_decoder_outlier_tokens_fp8_range_guard(amp, weights_for):
         assert err <= (3e-4 if amp < 400 else 1e-3), (amp, err)
     finally:
         eng.close()
+
+
+def test_fp8_range_guard_device_resident_path(weights_for):
+    """The device-resident forward (glc_engine_forward_device, what bench.py times) cannot be repeated behind the caller's back: when its
+    operands left the fp8 range, glc_engine_sync must FAIL with a message — never hand out logits at silent single-f16 accuracy — and the
+    engine must then run the split-f16 arithmetic, whose result matches the oracle."""
+    import oracle_c
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.engine import Engine
+    cfg, w0 = weights_for("dec-mini")
+    w = dict(w0)
+    emb = w0["embed_tokens.weight"].copy()
+    emb[16::16, 5] = 3000.0
+    w["embed_tokens.weight"] = emb
+    B, S, Cn = 3, 200, 3
+    ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=91, ragged=True)
+    ref = oracle_c.forward(cfg, w, ids, mask)
+    eng = Engine(cfg, w, dtype="f32")
+    d_ids = d_mask = d_out = None
+    try:
+        eng.set_group_split(2)
+        d_ids, d_mask, d_out = eng.dev_alloc(ids.nbytes), eng.dev_alloc(mask.nbytes), eng.dev_alloc(B * Cn * 4)
+        eng.h2d(d_ids, ids); eng.h2d(d_mask, mask)
+        eng.forward_device(d_ids, d_mask, B, S, Cn, d_out)
+        assert eng.last_mx()
+        with pytest.raises(RuntimeError, match="fp8 range"):
+            eng.sync()
+        assert eng.fp8_range_sticky()
+        eng.forward_device(d_ids, d_mask, B, S, Cn, d_out)       # the engine has left the MX pipeline: this one is good
+        eng.sync()
+        assert not eng.last_mx()
+        got = np.zeros((B, Cn), np.float32)
+        eng.d2h(got, d_out)
+        assert np.abs(sig(got) - sig(ref)).max() <= 1e-3
+    finally:
+        for p in (d_ids, d_mask, d_out):
+            if p:
+                eng.dev_free(p)
+        eng.close()

@@ -200,6 +200,15 @@ def test_c4_large_shard_b32_s1024(dtype, c_generated_weights):
         assert got.shape == (B, Cn) and np.isfinite(got).all()
         err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [5], _tol(dtype))
         print(f"c4 shard {dtype}: max |prob - oracle| on 1 row = {err:.2e} (bar {BAR})")
+        if dtype == "f32":                                               # the split-f16 arithmetic (GLICLASS_MX=0) of the same shape: ten times inside the bar
+            assert eng.last_mx()
+            eng.set_mx(False)
+            exact = eng.forward(ids, mask)
+            assert not eng.last_mx()
+            e2 = _check_rows_vs_oracle(cfg, w, ids, mask, exact, [5], TOL_DEFAULT_MODE)
+            print(f"c4 shard f32, GLICLASS_MX=0: {e2:.2e}; MX vs split over all {B * Cn} probabilities {np.abs(sig(got) - sig(exact)).max():.2e}")
+            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX
+            eng.set_mx(True)
         quarter = eng.forward(ids[8:16], mask[8:16])
         assert np.abs(sig(quarter) - sig(got[8:16])).max() <= (1e-5 if dtype == "f32" else 5e-3)
     finally:
@@ -220,6 +229,7 @@ def test_c5_decoder_b16_s2048(dtype, c_generated_weights):
         eng.set_length_buckets(1)
         got = eng.forward(ids, mask)
         assert got.shape == (B, Cn) and np.isfinite(got).all()
+        was_mx = eng.last_mx()
         pair = eng.forward(ids[6:8], mask[6:8])                          # row independence: two rows on their own
         # (f32: the two-row forward is small enough to take the plain-fp32 row format and the 128-tile kernels, the batch the
         #  group-split format and the 256-tile kernels: same arithmetic, other summation order — both sit ~1e-5 from the oracle)
@@ -229,5 +239,12 @@ def test_c5_decoder_b16_s2048(dtype, c_generated_weights):
             w = c_generated_weights(spec, cfg)
             err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [3], TOL_MX)
             print(f"c5 f32: max |prob - oracle| on 1 row = {err:.2e} (bar {BAR})")
+            assert was_mx
+            eng.set_mx(False)                                            # the split-f16 projections (GLICLASS_MX=0): ten times inside the bar
+            exact = eng.forward(ids, mask)
+            assert not eng.last_mx()
+            e2 = _check_rows_vs_oracle(cfg, w, ids, mask, exact, [3], TOL_DEFAULT_MODE)
+            print(f"c5 f32, GLICLASS_MX=0: {e2:.2e}; MX vs split over all {B * Cn} probabilities {np.abs(sig(got) - sig(exact)).max():.2e}")
+            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX
     finally:
         eng.close()

@@ -59,6 +59,7 @@ def test_mx_pipeline_odd_batch_shapes():
             assert not np.array_equal(got, ref)
             d = float(np.abs(sig(got) - sig(ref)).max())
             assert d <= 3e-4, (B, S, Cn, d)
+        assert eng.L.glc_debug_mx_weight_bytes(eng.h) > 11 * 4 * 7077888       # (base: 12 layers x ~7.1 M projection weights x 4 bytes, minus the pruned layer's folded copies)
     finally:
         eng.close()
 

@@ -691,7 +691,16 @@ def test_group_split_pipeline_vs_oracle_and_plain_fp32(cname, engines, weights_f
             assert np.abs(sig(mx) - sig(ref)).max() <= TOL_MX, (B, S)
             assert np.abs(sig(mx) - sig(gs)).max() <= TOL_MX, (B, S)
             assert not np.array_equal(mx, gs)
+            # ... and its attention on the bucket-space kernel (round 4, attention_mx2.hip; opt-in): short rows, rows longer than the table's
+            # linear range (S = 700, 1100: log buckets and saturation), a single query tile (S = 64), ragged lengths, rows without labels
+            eng.set_mx2(True)
+            mx2 = eng.forward(ids, mask)
+            eng.set_mx2(False)
+            assert eng.last_mx_attention() and np.isfinite(mx2).all()
+            assert np.abs(sig(mx2) - sig(ref)).max() <= TOL_MX, (B, S)
+            assert np.abs(sig(mx2) - sig(mx)).max() <= 1e-4, (B, S)
     finally:
         eng.set_group_split(1)
         eng.set_ln_fused(True)
         eng.set_mx(True)
+        eng.set_mx2(False)

@@ -75,7 +75,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 // time; GLC_ATTN_PV16=1 or variant bit 12, never the default.
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them; the stamps
 // pin the instruction order at each boundary, so the stamped build is slower than the one it describes).
-template <int NW, int ABL = 0, bool DIAG = false>
+template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     static_assert(NW == 8 || NW == 4, "workgroup shapes: 8 waves x 1 per CU, 4 waves x 2 per CU");
     constexpr int LROWP = 32 * (NW + 1) + 4;            // floats per p2c image row
@@ -407,10 +407,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             k_tile(kt, kf);
             float* img = p2c_img;
             f32x16 sacc;
+            // (odd steps: the 16 gather addresses (rr_base - kc) ^ 32 are no affine function of the lane's base; as loop invariants the compiler
+            //  spills them — 16 of the kernel's 19 spilled registers, reloaded through the vector-memory path every second tile, 119 MB of
+            //  scratch writes per launch (profiles/r04/attn_hbm_bytes.txt).  RECOMP (default since round 4): recompute them from an opaque copy of the
+            //  base instead — bit-identical, 7 spilled registers left, -1.5 % per launch in the microbenchmark)
+            int rbo = rr_base;
+            if constexpr (RECOMP) asm volatile("" : "+v"(rbo));
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kc = 16 * (i >> 3) + (i & 7);
-                sacc[i] = xr ? c2p_l[c * LROW + ((rr_base - kc) ^ 32)] : c2p_even[-kc];
+                sacc[i] = xr ? c2p_l[c * LROW + (((RECOMP ? rbo : rr_base) - kc) ^ 32)] : c2p_even[-kc];
             }
             // ---- p2c: low block of this wave, and, one wave per tile, the high block of the last wave ----
             f32x16 bacc, bacc2;
@@ -553,7 +559,9 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     static const bool pv16_env = glc_dev_env("GLC_ATTN_PV16") && atoi(glc_dev_env("GLC_ATTN_PV16")) != 0;
     static std::atomic<unsigned> r5{0};
     if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
-    return go(attn_mx_kernel<NW, 0>, r0);
+    static std::atomic<unsigned> r6{0};
+    if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
+    return go(attn_mx_kernel<NW, 0, false, true>, r0);
 }
 }  // namespace
 

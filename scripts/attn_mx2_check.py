@@ -25,7 +25,7 @@ for (B, S) in shapes:
         Sp = (S + 63) // 64 * 64
         rows = B * Sp
         out = {}
-        for v in (128, 128 | 8192):
+        for v in (128, 128 | 8192, 128 | 16384):
             cs = (ctypes.c_double * 2)()
             ms = e.L.glc_debug_attn_bench(e.h, 2, v, 0, cs)
             if ms < 0:
@@ -35,6 +35,7 @@ for (B, S) in shapes:
                 print("ERR", e.L.glc_last_error().decode()); sys.exit(1)
             out[v] = buf.reshape(B, Sp, cfg.hidden)
         a, b = out[128], out[128 | 8192]
+        print("  band kernel with recomputed gather addresses identical to the spilling build:", np.array_equal(out[128], out[128 | 16384]))
         valid = np.zeros((B, Sp), bool); valid[:, :S] = mask.astype(bool)      # rows whose query is attended (others are don't-care)
         d = np.abs(a - b)[valid]
         scale = np.abs(a[valid]).max()
@@ -47,7 +48,7 @@ e.L.glc_debug_set_stop(e.h, 1)
 e.forward(ids, mask)
 flops = B * S * (4.0 * S * cfg.hidden + 4.0 * P * cfg.hidden)
 for rep in range(3):
-    for v in [128, 128 | 8192] + [128 | 8192 | int(x) for x in os.environ.get('GLC_ABL', '').split(',') if x]:
+    for v in [128, 128 | 8192] + [128 | int(x) for x in os.environ.get("GLC_BANDV", "").split(",") if x] + [128 | 8192 | int(x) for x in os.environ.get('GLC_ABL', '').split(',') if x]:
         cs = (ctypes.c_double * 2)()
         ms = e.L.glc_debug_attn_bench(e.h, 20, v, stamps if rep == 0 else 0, cs)
         print(f"variant {v}: {ms:.4f} ms  {flops/ms/1e9:7.1f} TF (algorithmic)", flush=True)

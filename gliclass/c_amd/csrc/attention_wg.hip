@@ -427,10 +427,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
             float* img = p2c_img + (KVG ? (size_t)(kt & 1) * 32 * LROWP : (size_t)grp * 32 * LROWP);      // KVG: two images, alternating; STAG: one per half
             // the gathered c2p band is the initial accumulator of S^T; reg i <-> key k0 + 16 (i>>3) + 8h + (i&7)
             f32x16 sacc;
+            int rbo = rr_base;            // (round 4, as attention_mx.hip: the odd step's 16 gather addresses recomputed from an opaque copy of the
+            if constexpr (SPLIT) asm volatile("" : "+v"(rbo));      //  base instead of living as spilled loop invariants; bit-identical)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kc = 16 * (i >> 3) + (i & 7);
-                if constexpr (SPLIT) sacc[i] = xr ? c2p_l[c * LROW + ((rr_base - kc) ^ 32)] : c2p_even[-kc];
+                if constexpr (SPLIT) sacc[i] = xr ? c2p_l[c * LROW + ((rbo - kc) ^ 32)] : c2p_even[-kc];
                 else sacc[i] = xr ? *c2p_odd[i] : c2p_even[-kc];
             }
             // ---- p2c (needs only K and PQ): low block of this wave, and, one wave per tile, the high block of the last wave ----

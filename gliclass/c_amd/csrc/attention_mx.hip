@@ -553,7 +553,7 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
         return nullptr;
     };
     static std::atomic<unsigned> r0{0}, r1{0}, r2{0}, r4{0};
-    if (a.stamps) return go(attn_mx_kernel<NW, 0, true>, r4);
+    if (a.stamps) return go(attn_mx_kernel<NW, 0, true, true>, r4);
     if (a.variant & 256) return go(attn_mx_kernel<NW, 1>, r1);
     if (a.variant & 512) return go(attn_mx_kernel<NW, 2>, r2);
     static const bool pv16_env = glc_dev_env("GLC_ATTN_PV16") && atoi(glc_dev_env("GLC_ATTN_PV16")) != 0;

@@ -262,6 +262,236 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mx_kernel(const unsigned char
         }
 }
 
+
+// ---- the same attention with K and V^T through LDS (the default) ----
+// attn_gqa_mx_kernel above loads every K and V^T tile per wave: 32 KiB per wave and key tile at head_dim 128 through the CU's 64 B/clk
+// vector-memory path — 4096 cycles per tile round of 8 waves against 2048 of matrix pipe: the path, not the pipe, bounds it.  The four waves
+// of a workgroup are four consecutive query tiles of ONE query head, so they walk the same K / V^T tiles: here each tile is fetched once
+// per workgroup by LDS-DMA (8 one-KiB pieces per wave and tile instead of 32 loads) into two-slot rings (K 2 x 16 KiB, V^T 2 x 16 KiB at
+// head_dim 128; two workgroups per CU) and read as fragments by all four, with the protocol of attention_mx2.hip: ONE workgroup barrier per
+// key tile — after barrier(t) every wave holds its K(t) fragments and has left V^T(t - 1), so V^T(t + 1) and K(t + 2) are requested there, each
+// wave waits for its own pieces right before barrier(t + 1), which publishes them.  Causal: a wave's query tile ends the walk at its own
+// diagonal; waves that are done (or have no tile, or a padding-only one) keep moving their pieces and meeting the barriers until the
+// workgroup's longest walk ends.  MX steps land re-arranged as [64 lanes x first 16 B | 64 lanes x second] (per-lane DMA source address).
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_dmx[];
+
+__device__ __forceinline__ void glds16_sv(const unsigned char* ubase, unsigned lane_off, void* l) {      // attention_wg.hip
+    const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)l;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(lane_off), "s"(ubase) : "memory");
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_gqa_mx_ring_kernel(const unsigned char* __restrict__ Qm, const unsigned char* __restrict__ Km, const unsigned char* __restrict__ Vm,
+                                                                  const float* __restrict__ kbias, const int* __restrict__ klen, const int* __restrict__ kfirst_,
+                                                                  unsigned char* __restrict__ CTX, int B, int Sp, int nq, int nkv, int causal, unsigned* gx_sat) {
+    constexpr int NS = D / 16, NM = D / 32, ND = D / 32, TILE = 32 * D * 4, P4 = D / 32;      // P4: one-KiB pieces per wave and tile of K (and of V^T)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int nt = Sp >> 5, nqb = (nt + 3) >> 2, grp = nq / nkv;
+    const int SC = h ? (127 | ((127 - GLC_GX_SHIFT) << 8)) : ((127 - GLC_GX_SHIFT) | (127 << 8));
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int per = grp * nqb;
+    const int bg = xcd + 8 * (jj / per), rem = jj % per;
+    if (bg >= B * nkv) return;                               // (workgroup-uniform)
+    const int b = bg / nkv, g = bg - b * nkv;
+    const int hq = g * grp + rem / nqb;
+    const int qt = nt - 1 - ((rem % nqb) * 4 + wave);       // longest tiles first within a head; wave 0 holds the workgroup's last query tile
+    const int q0 = qt * 32;
+    const int kl = klen[b];
+    int nkt_len = (kl + 31) >> 5;
+    nkt_len = nkt_len < 1 ? 1 : (nkt_len > nt ? nt : nkt_len);
+    const bool has_tile = qt >= 0;
+    const bool pad_only = has_tile && q0 >= kl && q0 > 0;   // padding-only query tile of a ragged batch: zeros out, no walk
+    const bool active = has_tile && !pad_only;
+    const int nkt = !active ? 0 : (causal && nkt_len > qt + 1 ? qt + 1 : nkt_len);       // this wave's walk
+    // the workgroup's walk = the longest of its waves' (walks grow with the query tile: the first active wave has it)
+    __shared__ int s_nkt[4];
+    if (lane == 0) s_nkt[wave] = nkt;
+    __syncthreads();
+    const int nkt_wg = max(max(s_nkt[0], s_nkt[1]), max(s_nkt[2], s_nkt[3]));
+
+    unsigned char* row = CTX + ((size_t)b * Sp + (has_tile ? q0 : 0) + c) * 4 * ((size_t)nq * D);
+    if (pad_only) {
+        unsigned char* z = row + (size_t)hq * D * 4 + h * (D * 2);
+#pragma unroll
+        for (int i = 0; i < D / 8; ++i) *reinterpret_cast<u32x4*>(z + 16 * i) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if (nkt_wg == 0) return;                                 // (workgroup-uniform: nobody walks)
+
+    const unsigned char* __restrict__ Qp = Qm + ((size_t)(b * nq + hq) * nt + (has_tile ? qt : 0)) * TILE;
+    const unsigned char* __restrict__ Kp = Km + (size_t)(b * nkv + g) * nt * TILE;
+    const unsigned char* __restrict__ Vp = Vm + (size_t)(b * nkv + g) * nt * TILE;
+    const float* __restrict__ kb = kbias + (size_t)b * Sp;
+    const int kfirst = kfirst_[b];
+    const int foff = 8 * h;
+    unsigned char* const kring = smem_dmx;                   // 2 x TILE
+    unsigned char* const vring = smem_dmx + 2 * TILE;        // 2 x TILE
+
+    // LDS-DMA: wave w moves pieces P4 w .. P4 w + P4 - 1 of the K tile and of the V^T tile
+    const unsigned off16 = lane * 16, off32 = lane * 32;
+    auto uniform_ptr = [](const unsigned char* q) -> const unsigned char* {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
+    };
+    auto dma_k = [&](int t) __attribute__((always_inline)) {
+        const unsigned char* src = Kp + (size_t)t * TILE;
+        unsigned char* dst = kring + (size_t)(t & 1) * TILE;
+#pragma unroll
+        for (int i = 0; i < P4; ++i) {
+            const int p = P4 * wave + i;                     // K tile: pieces 0 .. NS - 1 the f16 units, then two per MX step
+            if (p < NS) glds16_sv(uniform_ptr(src + p * 1024), off16, dst + p * 1024);
+            else { const int q = p - NS; glds16_sv(uniform_ptr(src + NS * 1024 + (q >> 1) * 2048 + 16 * (q & 1)), off32, dst + NS * 1024 + (q >> 1) * 2048 + (q & 1) * 1024); }
+        }
+    };
+    auto dma_v = [&](int t) __attribute__((always_inline)) {
+        const unsigned char* src = Vp + (size_t)t * TILE;
+        unsigned char* dst = vring + (size_t)(t & 1) * TILE;
+#pragma unroll
+        for (int i = 0; i < P4; ++i) {
+            const int p = P4 * wave + i, a = p >> 2, r = p & 3;      // V^T tile: per 4-KiB sub-tile [f16 unit | f16 unit | MX step = two pieces]
+            if (r < 2) glds16_sv(uniform_ptr(src + a * 4096 + r * 1024), off16, dst + a * 4096 + r * 1024);
+            else glds16_sv(uniform_ptr(src + a * 4096 + 2048 + 16 * (r - 2)), off32, dst + a * 4096 + 2048 + (r - 2) * 1024);
+        }
+    };
+
+    f16x8 qf[NS];
+    i32x8 qx[NM];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const f16x8*>(Qp + s * 1024 + lane * 16);
+#pragma unroll
+        for (int mm = 0; mm < NM; ++mm) qx[mm] = cat8(*reinterpret_cast<const i32x4*>(Qp + NS * 1024 + mm * 2048 + lane * 32), *reinterpret_cast<const i32x4*>(Qp + NS * 1024 + mm * 2048 + lane * 32 + 16));
+    }
+    dma_k(0);
+    dma_v(0);
+    if (nkt_wg > 1) dma_k(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // K(0) is in the ring for everyone (K(1), V^T(0): published by barrier(0))
+
+    f32x16 o[ND];
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[a][i] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+    float one_f = 1.0f;
+    asm volatile("" : "+s"(one_f));
+
+    for (int kt = 0; kt < nkt_wg; ++kt) {
+        const bool work = kt < nkt;                          // wave-uniform: this wave's walk still covers key tile kt
+        float sv[16];
+        if (work) {
+            const unsigned char* ktile = kring + (size_t)(kt & 1) * TILE;
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(ktile + s * 1024 + lane * 16), qf[s], sacc, 0, 0, 0);
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm) {
+                const i32x8 kx = cat8(*reinterpret_cast<const i32x4*>(ktile + NS * 1024 + mm * 2048 + lane * 16), *reinterpret_cast<const i32x4*>(ktile + NS * 1024 + mm * 2048 + 1024 + lane * 16));
+                sacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kx, qx[mm], sacc, 0, 0, 0, SC, 1, SC);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[i] = sacc[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // my pieces of V^T(kt) and K(kt + 1), requested a tile ago; my K(kt) fragment reads
+        __builtin_amdgcn_s_barrier();                                    // barrier(kt)
+        if (kt + 1 < nkt_wg) dma_v(kt + 1);
+        if (kt + 2 < nkt_wg) dma_k(kt + 2);
+        if (!work) continue;
+        const int k0 = kt * 32;
+        if (k0 + 32 > kfirst) {                                             // wave-uniform: tile holds masked keys
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(kb + k0 + foff);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(kb + k0 + foff + 4);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(kb + k0 + 16 + foff + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sv[i] += b0[i]; sv[4 + i] += b1[i]; sv[8 + i] += b2[i]; sv[12 + i] += b3[i]; }
+        }
+        if (causal && kt == qt) {                                           // diagonal tile: key offset > query offset is masked
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ko = 16 * (i >> 3) + foff + (i & 7);
+                if (ko > c) sv[i] = GLC_NEG_BIG;
+            }
+        }
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+        mx = fmaxf(mx, sv[15]);
+        if (__builtin_amdgcn_ballot_w64(mx - m > DEC_RESCALE_THR) != 0ull) {   // deferred rescale (attention.hip)
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+            m = mnew;
+            l *= alpha;
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[a][i] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(sv[i] - m); psum += sv[i]; }
+        l += psum;
+        f16x8 pf[2];
+        i32x8 px;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[t][j] = (f16_t)sv[8 * t + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q], sv[4 * q + 1], 0, false);
+            wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q + 2], sv[4 * q + 3], wh, true);
+            px[q] = wh;
+            float r[4];
+            const i32x4 pfw = __builtin_bit_cast(i32x4, pf[q >> 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pw = pfw[2 * (q & 1) + (e >> 1)];
+                if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * q + e]), "s"(one_f), "v"(pw));
+                else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * q + e]), "s"(one_f), "v"(pw));
+            }
+            typedef short v2i16 __attribute__((ext_vector_type(2)));
+            v2i16 wl2 = {0, 0};
+            wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[0], r[1], 1.0f / (float)(1 << GLC_GX_SHIFT), false);
+            wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[2], r[3], 1.0f / (float)(1 << GLC_GX_SHIFT), true);
+            px[4 + q] = __builtin_bit_cast(int, wl2);
+        }
+        const unsigned char* vtile = vring + (size_t)(kt & 1) * TILE;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            const f16x8 v0 = *reinterpret_cast<const f16x8*>(vtile + a * 4096 + lane * 16);
+            const f16x8 v1 = *reinterpret_cast<const f16x8*>(vtile + a * 4096 + 1024 + lane * 16);
+            const i32x8 vx = cat8(*reinterpret_cast<const i32x4*>(vtile + a * 4096 + 2048 + lane * 16), *reinterpret_cast<const i32x4*>(vtile + a * 4096 + 3072 + lane * 16));
+            o[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[0], o[a], 0, 0, 0);
+            o[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[1], o[a], 0, 0, 0);
+            o[a] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o[a], 0, 0, 0, SC, 1, SC);
+        }
+    }
+    if (!active) return;
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float own_a = o[a][8 * p + e] * inv, own_b = o[a][8 * p + 4 + e] * inv;
+                const float got = __shfl_xor(h ? own_a : own_b, 32, 64);
+                v[e] = h ? got : own_a;
+                v[4 + e] = h ? own_b : got;
+            }
+            gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), gx_sat);
+        }
+}
+
 }  // namespace
 
 // RoPE + softmax scale + MX tiles of the fused fp32 projection.  Sp % 64 == 0, d in {64, 128}; Qm / Km / Vm: 4 bytes per element.
@@ -282,6 +512,19 @@ const char* glc_launch_attention_gqa_mx(hipStream_t st, const void* Qm, const vo
     const int nt = Sp / 32, nqb = (nt + 3) / 4, per = (nq / nkv) * nqb, bg8 = (B * nkv + 7) / 8 * 8;
     const dim3 grid(per * bg8), block(256);
     unsigned* sat = glc_gx_sat_ptr();
+    static const bool direct = glc_dev_env("GLC_DEC_ATTN_DIRECT") && atoi(glc_dev_env("GLC_DEC_ATTN_DIRECT")) != 0;      // developer A/B: K / V^T per wave from memory
+    if (!direct) {
+        const size_t lds = (size_t)4 * 32 * d * 4;            // K ring + V^T ring, two slots each
+        static std::atomic<unsigned> ok128{0}, ok64{0};
+        if (d == 128) {
+            if (!glc_raise_lds_limit(attn_gqa_mx_ring_kernel<128>, (int)lds, ok128)) return "attention_gqa_mx: cannot raise the dynamic LDS limit";
+            hipLaunchKernelGGL(attn_gqa_mx_ring_kernel<128>, grid, block, lds, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
+        } else {
+            if (!glc_raise_lds_limit(attn_gqa_mx_ring_kernel<64>, (int)lds, ok64)) return "attention_gqa_mx: cannot raise the dynamic LDS limit";
+            hipLaunchKernelGGL(attn_gqa_mx_ring_kernel<64>, grid, block, lds, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
+        }
+        return nullptr;
+    }
     if (d == 128) hipLaunchKernelGGL(attn_gqa_mx_kernel<128>, grid, block, 0, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
     else hipLaunchKernelGGL(attn_gqa_mx_kernel<64>, grid, block, 0, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
     return nullptr;

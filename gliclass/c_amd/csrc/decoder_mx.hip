@@ -27,20 +27,6 @@ __device__ __forceinline__ i32x8 cat8(const i32x4& a, const i32x4& b) {
     return r;
 }
 
-// 8 consecutive values of one row: the 16-byte f16 piece and the two 8-byte fp8 pieces (hl: (hi8 | lo8), else (lo8 | hi8))
-__device__ __forceinline__ void store_mx8(unsigned char* f16_dst, unsigned char* mx_dst, const float (&v)[8], bool hl, unsigned* sat) {
-    gx_range_note(v, 1.0f, sat);
-    gs_h8 hi;
-    float lo[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const f16_t hv = (f16_t)v[j]; hi[j] = hv; lo[j] = (v[j] - (float)hv) * (float)(1 << GLC_GX_SHIFT); }
-    const u32x2 l8 = {glc_fp8x4(lo[0], lo[1], lo[2], lo[3]), glc_fp8x4(lo[4], lo[5], lo[6], lo[7])};
-    const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
-    *reinterpret_cast<gs_h8*>(f16_dst) = hi;
-    *reinterpret_cast<u32x2*>(mx_dst) = hl ? h8 : l8;
-    *reinterpret_cast<u32x2*>(mx_dst + 16) = hl ? l8 : h8;
-}
-
 template <int D>
 __global__ __launch_bounds__(256) void qkv_layout_mx_kernel(const float* __restrict__ QKV, const float* __restrict__ cs, unsigned char* __restrict__ Qm,
                                                             unsigned char* __restrict__ Km, unsigned char* __restrict__ Vm, int Sp, int nq, int nkv, float qscale,

@@ -51,6 +51,7 @@ struct DecLayerW {                     // decoder-style backbone (decoder.hip)
     void *Wqkvf = nullptr, *Wguf = nullptr;                                   // fp32 mode, RMSNorm folded into the GEMMs: Wqkv diag(ln1), Wgu diag(ln2), group-split
     void *Wqkvf_x = nullptr, *Wo_x = nullptr, *Wguf_x = nullptr, *Wd_x = nullptr;   // MX pipeline: the same four as GX rows + their fp8 exponents
     int ws_qkvf = 0, ws_o = 0, ws_guf = 0, ws_d = 0;
+    float* bqkv_p = nullptr;            // bqkv in the row order of a Wqkvf_x built for the RoPE epilogue (glc_rope_perm128), else null
 };
 
 struct LayerW {
@@ -83,6 +84,7 @@ struct glc_engine {
     size_t mx_bytes = 0;                 // their size (glc_debug_mx_weight_bytes)
     bool last_mx = false;                // the last forward ran the MX pipeline
     bool last_mx_attn = false;           // ... and its attention ran on MX tiles (attention_mx.hip)
+    bool dec_rope_epi = true;            // decoder MX pipeline: RoPE + MX tiles as the QKV projection's epilogue (gemm256x EPI_QKVR); GLC_DEC_ROPE_EPI=0: the separate pass
     bool mx_attn = true;                 // MX pipeline: attention on MX tiles (attention_mx.hip); false: split-f16 units (GLC_MX_ATTN=0, glc_debug_set_mx_attention)
     int debug_stop = -1;                 // developer: leave run_forward after stage (10 * layer + k), k = 0 QKV, 1 attention, 2 attn-out, 3 FFN1, 4 FFN2 (+ LayerNorm): workspace inspection
     int prec_mask = 0;              // precision-budget switches (PM_* of glc_kernels.h; glc_debug_set_precision_mask): operands rounded to f16 in the group-split pipeline
@@ -423,9 +425,30 @@ bool build_mx_weights(glc_engine* e) {
     const size_t H = c.hidden, I = c.inter;
     if (c.backbone == GLC_BACKBONE_DECODER) {
         const size_t NQ = (size_t)c.heads * c.head_dim, NQKV = NQ + 2 * (size_t)c.kv_heads * c.head_dim;
-        for (auto& w : e->dlayers)
+        // RoPE + MX tiles as the epilogue of the QKV projection (gemm256x EPI_QKVR; head_dim 128, even head counts): the rows of every Q / K head
+        // of the GX copy (and a copy of the bias) go into the order glc_rope_perm128 names — 32-row blocks 1 and 2 of the head trade places
+        const bool rope_epi = e->dec_rope_epi && c.head_dim == 128 && c.heads % 2 == 0 && c.kv_heads % 2 == 0;
+        void* tmp = nullptr;
+        const size_t blk = (size_t)32 * H * sizeof(float);        // 32 GX rows
+        if (rope_epi) { tmp = dmalloc(e, blk, false); if (!tmp) return false; }
+        for (auto& w : e->dlayers) {
             if (!copy(w.Wqkvf, NQKV * H, w.Wqkvf_x, w.ws_qkvf) || !copy(w.Wo, H * NQ, w.Wo_x, w.ws_o) ||
-                !copy(w.Wguf, 2 * I * H, w.Wguf_x, w.ws_guf) || !copy(w.Wd, H * I, w.Wd_x, w.ws_d)) return false;
+                !copy(w.Wguf, 2 * I * H, w.Wguf_x, w.ws_guf) || !copy(w.Wd, H * I, w.Wd_x, w.ws_d)) { dfree(e, tmp); return false; }
+            if (!rope_epi) continue;
+            w.bqkv_p = (float*)dmalloc(e, NQKV * sizeof(float), false);
+            if (!w.bqkv_p) { dfree(e, tmp); return false; }
+            HIPCHK(hipMemcpyAsync(w.bqkv_p, w.bqkv, NQKV * sizeof(float), hipMemcpyDeviceToDevice, e->stream), false);
+            for (int hd = 0; hd < c.heads + c.kv_heads; ++hd) {
+                char* r1 = (char*)w.Wqkvf_x + ((size_t)hd * 128 + 32) * H * sizeof(float);
+                char* r2 = r1 + blk;
+                HIPCHK(hipMemcpyAsync(tmp, r1, blk, hipMemcpyDeviceToDevice, e->stream), false);
+                HIPCHK(hipMemcpyAsync(r1, r2, blk, hipMemcpyDeviceToDevice, e->stream), false);
+                HIPCHK(hipMemcpyAsync(r2, tmp, blk, hipMemcpyDeviceToDevice, e->stream), false);
+                HIPCHK(hipMemcpyAsync(w.bqkv_p + hd * 128 + 32, w.bqkv + hd * 128 + 64, 32 * sizeof(float), hipMemcpyDeviceToDevice, e->stream), false);
+                HIPCHK(hipMemcpyAsync(w.bqkv_p + hd * 128 + 64, w.bqkv + hd * 128 + 32, 32 * sizeof(float), hipMemcpyDeviceToDevice, e->stream), false);
+            }
+        }
+        if (tmp) { HIPCHK(hipStreamSynchronize(e->stream), false); dfree(e, tmp); }
     } else {
         for (size_t l = 0; l < e->layers.size(); ++l) {
             LayerW& w = e->layers[l];
@@ -555,10 +578,17 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
         g.A = e->H1; g.W = w.Wqkv; g.bias = w.bqkv; g.C = e->QKV; g.Mpad = Mpad; g.N = NQKV; g.K = H; g.gs_c_plain = 1;
         if (rnf) { g.A = X; g.W = w.Wqkvf; g.a_stats = sX; }
         if (mx) { g.W = w.Wqkvf_x; g.mx_ws = w.ws_qkvf; }
-        { Prof p(e, PC_QKV); KCHK(gs ? gemm_gs(EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
+        const bool perm = mx && w.bqkv_p;            // Wqkvf_x rows in the RoPE-epilogue order
+        if (perm) { g.bias = w.bqkv_p; g.perm_cols = (nq + nkv) * d; }
+        const bool rope_epi = perm && mxa;           // Q2:206-211 in one launch: projection, RoPE, scale, MX tiles (gemm256x.hip EPI_QKVR)
+        if (rope_epi) { g.rope_cs = e->ropes[Sp]; g.qscale = qscale; g.nq = nq; g.nkv = nkv; g.Sp = Sp; g.Mvalid = M; g.Qh = e->Qh; g.Kh = e->Kh; g.Vt = e->Vt; }
+        { Prof p(e, PC_QKV);
+          if (rope_epi) KCHK(gemm_gs(EPI_QKVR, g), false);
+          else {
+          KCHK(gs ? gemm_gs(EPI_BIAS, g) : launch_gemm_auto(e, dt, EPI_BIAS, g), false);        // Q2:206-208
           if (mxa) KCHK(glc_launch_qkv_layout_mx(st, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);     // Q2:211 RoPE, MX tiles (decoder_mx.hip)
           else if (mfma) KCHK(glc_launch_qkv_layout(st, dt, e->QKV, e->ropes[Sp], e->Qh, e->Kh, e->Vt, B, Sp, nq, nkv, d, qscale), false);   // Q2:211 RoPE
-          else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); }
+          else KCHK(glc_launch_rope_qk(st, dt, e->QKV, e->ropes[Sp], M, Sp, nq, nkv, d, qscale), false); } }
         { Prof p(e, PC_ATTN);
           if (mxa) KCHK(glc_launch_attention_gqa_mx(st, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal), false);
           else if (mfma) KCHK(glc_launch_attention_gqa_mfma(st, dt, e->Qh, e->Kh, e->Vt, e->kbias, e->klen, e->kfirst, e->CTX, B, Sp, nq, nkv, d, c.causal, mx ? 2 : (gs ? 1 : 0)), false);
@@ -994,6 +1024,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         e->mx_built = eligible && !(mv && !strcmp(mv, "0"));
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
         if (const char* av = glc_dev_env("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
+        if (const char* av = glc_dev_env("GLC_DEC_ROPE_EPI")) e->dec_rope_epi = atoi(av) != 0;      // developer A/B switch
         if (const char* av = glc_dev_env("GLC_ATTN_MX2")) e->mx2 = atoi(av) != 0;         // developer A/B switch: 1 = the bucket-space kernel (attention_mx2.hip)
     }
     if (const char* gv = glc_dev_env("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch

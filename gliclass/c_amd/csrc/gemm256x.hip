@@ -41,19 +41,12 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
 }
 
-template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int c32 = lane & 31, h = lane >> 5;
-    const int K = p.K, N = p.N;
-    const unsigned long long t_entry = DIAG ? __builtin_amdgcn_s_memtime() : 0;
-
-    // XCD-aware tile order (gemm256s.hip)
+// XCD-aware tile order (gemm256s.hip): this workgroup's (M-tile, N-tile) of a launch over ntn N-tiles
+__device__ __forceinline__ void x_tile_of_block(const GemmArgs& p, int ntn, int& mt, int& nt) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    int mt = tile / ntn, nt = tile % ntn;
+    mt = tile / ntn; nt = tile % ntn;
     if (p.n_group > 0) {
         const int mts = nwg / ntn, mpx = mts >> 3, nb = p.n_group;
         const int i = bid >> 3, per = mpx * nb;
@@ -61,6 +54,18 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
         mt = xcd * mpx + r / nb;
         nt = cg * nb + r % nb;
     }
+}
+
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0>
+__device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, int ntn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int c32 = lane & 31, h = lane >> 5;
+    const int K = p.K, N = p.N;
+    const unsigned long long t_entry = DIAG ? __builtin_amdgcn_s_memtime() : 0;
+
+    int mt, nt;
+    x_tile_of_block(p, ntn, mt, nt);
     const int m0 = mt * TM, n0 = (n_tile0 + nt) * TN;
     if constexpr (EPI == EPI_QKV && !VMODE) {
         if (p.q_tile_flag && n0 < p.H) {                // Q third, pruned last layer: nobody reads query tiles without selected rows
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
     typedef __attribute__((ext_vector_type(8))) T vec8T;
     const float* __restrict__ bias = p.bias;
     float* stg = reinterpret_cast<float*>(smem256x + wave * EPI_PATCH);
-    const int qkv_b0 = (EPI == EPI_QKV) ? m0 / p.Sp : 0;
+    const int qkv_b0 = (EPI == EPI_QKV || EPI == EPI_QKVR) ? m0 / p.Sp : 0;
     constexpr float kHi = 1.0f, kLo = (float)(1 << GLC_GX_SHIFT), kInvLo = 1.0f / (float)(1 << GLC_GX_SHIFT);       // activation rows: exponent 0
     if constexpr (EPI == EPI_SWIGLU) {
         // W rows alternate 16 gate / 16 up features (engine.hip interleaves them at load): in D[n = 32 J + 8 q + 4 h + e][m] the register quads
@@ -326,6 +331,44 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (EPI == EPI_QKVR) {
+                // Decoder Q / K heads (head_dim 128): this wave's 64 columns are features [32 hf, 32 hf + 32) (patch columns 0 .. 31) and their
+                // rotate-half partners 64 + the same (columns 32 .. 63) of one head (W rows in glc_rope_perm128 order).  A lane takes 8
+                // consecutive pairs of one row: RoPE (Q2:211) and, on Q, the softmax scale in fp32, then the two 8-value pieces of the MX
+                // tile (decoder_mx.hip layout; Q as (hi8 | lo8) at slot r, K as (lo8 | hi8) at slot pi(r)).
+                const int col0 = n0 + wn * 64, head = col0 >> 7, hf = (col0 >> 6) & 1;
+                const bool isq = head < p.nq;
+                const int ntl = p.Sp >> 5;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = lane + 64 * k, row = idx >> 2, g4 = idx & 3;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * 68 + g4 * 8), a1 = *reinterpret_cast<const f32x4*>(stg + row * 68 + g4 * 8 + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(stg + row * 68 + 32 + g4 * 8), b1 = *reinterpret_cast<const f32x4*>(stg + row * 68 + 32 + g4 * 8 + 4);
+                    const int m = m0 + wm * 128 + c * 32 + row;
+                    if (m >= p.Mvalid) continue;
+                    int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
+                    while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                    const float x1[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, x2[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    const int d1 = 32 * hf + g4 * 8, d2 = d1 + 64;
+                    const f32x4* cp = reinterpret_cast<const f32x4*>(p.rope_cs + ((size_t)sq * 64 + d1) * 2);
+                    const f32x4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                    const float cs[16] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3], c2[0], c2[1], c2[2], c2[3], c3[0], c3[1], c3[2], c3[3]};
+                    const float sc = isq ? p.qscale : 1.f;
+                    float o1[8], o2[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float co = cs[2 * j], sn = cs[2 * j + 1];
+                        o1[j] = (x1[j] * co - x2[j] * sn) * sc;
+                        o2[j] = (x2[j] * co + x1[j] * sn) * sc;
+                    }
+                    const int r = sq & 31, slot = isq ? r : glc_pi32(r);
+                    unsigned char* base = isq ? reinterpret_cast<unsigned char*>(p.Qh) + ((size_t)(b * p.nq + head) * ntl + (sq >> 5)) * 16384
+                                              : reinterpret_cast<unsigned char*>(p.Kh) + ((size_t)(b * p.nkv + (head - p.nq)) * ntl + (sq >> 5)) * 16384;
+                    unsigned* sat = m < p.gx_rows ? p.gx_sat : nullptr;
+                    store_mx8(base + (d1 >> 4) * 1024 + (32 * ((d1 >> 3) & 1) + slot) * 16, base + 8192 + (d1 >> 5) * 2048 + (32 * ((d1 >> 4) & 1) + slot) * 32 + 8 * ((d1 >> 3) & 1), o1, isq, sat);
+                    store_mx8(base + (d2 >> 4) * 1024 + (32 * ((d2 >> 3) & 1) + slot) * 16, base + 8192 + (d2 >> 5) * 2048 + (32 * ((d2 >> 4) & 1) + slot) * 32 + 8 * ((d2 >> 3) & 1), o2, isq, sat);
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k, row = idx >> 3, g8 = idx & 7;
@@ -395,11 +438,13 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                     }
                 } else {
                     if (p.gs_c_plain) {
-                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + n;
+                        const int nl = n < p.perm_cols ? (n & ~127) | glc_rope_perm128(n & 127) : n;      // (W rows in the EPI_QKVR order: back to the logical column)
+                        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + nl;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                     } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, m < p.gx_rows ? p.gx_sat : nullptr);      // FFN1's intermediate: streams (non-temporal)
                 }
+            }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -446,6 +491,14 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
                 if (m < p.Mvalid) {
                     int b = qkv_b0, sq = m - qkv_b0 * p.Sp;
                     while (sq >= p.Sp) { sq -= p.Sp; ++b; }
+                    if constexpr (EPI == EPI_QKVR) {      // decoder V^T MX tiles (decoder_mx.hip): D / 32 sub-tiles of 4 KiB per 32-key tile, (lo8 | hi8)
+                        const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const int col0 = n0 + wn * 64, g = (col0 >> 7) - p.nq - p.nkv, ddl = 64 * ((col0 >> 6) & 1) + dd, kgt = (sq & 31) >> 3;
+                        unsigned char* sub = reinterpret_cast<unsigned char*>(p.Vt) + ((size_t)(b * p.nkv + g) * (p.Sp >> 5) + (sq >> 5)) * 16384 + (ddl >> 5) * 4096;
+                        store_mx8(sub + (kgt >> 1) * 1024 + (32 * (kgt & 1) + (ddl & 31)) * 16, sub + 2048 + (32 * (kgt & 1) + (ddl & 31)) * 32 + 8 * (kgt >> 1), x8, false,
+                                  m < p.gx_rows ? p.gx_sat : nullptr);
+                        continue;
+                    }
                     if (p.qkv_mxt) {            // V^T MX tiles: (lo8 | hi8)
                         const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         gx_range_note(x8, kHi, p.gx_sat);
@@ -479,6 +532,18 @@ __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile
             o[1] = __builtin_amdgcn_s_memtime() - t_loop1;
         }
     }
+}
+
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) { gemm256x_tile<EPI, VMODE, DIAG, ABL>(p, n_tile0, ntn); }
+
+// Decoder QKV with the RoPE / MX-tile epilogue in ONE launch: the N-tiles of the V heads (nt >= nqk) run the transposed tile (c5: 7 + 1 N-tiles x
+// 128 M-tiles = 4 full rounds of the chip; as two launches the V heads' 128 workgroups would be a fifth, half-empty round)
+__global__ __launch_bounds__(512, 2) void gemm256x_qkvr_kernel(GemmArgs p, int nqk, int ntn) {
+    int mt, nt;
+    x_tile_of_block(p, ntn, mt, nt);
+    if (nt < nqk) gemm256x_tile<EPI_QKVR, false>(p, 0, ntn);
+    else gemm256x_tile<EPI_QKVR, true>(p, 0, ntn);
 }
 
 template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
@@ -569,6 +634,8 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
     if (!(a.Mpad > 0 && a.Mpad % TM == 0 && a.N > 0 && a.N % TN == 0 && a.K > 0 && a.K % 32 == 0)) return false;
     if (a.mx_ws < -40 || a.mx_ws > 60) return false;
     if (epi == EPI_QKV) return a.H % 256 == 0 && a.N == 3 * a.H && a.Sp % 64 == 0 && a.Sp >= 64 && a.nh * 64 == a.H;
+    if (epi == EPI_QKVR) return a.nq > 0 && a.nkv > 0 && a.nq % 2 == 0 && a.nkv % 2 == 0 && a.N == (a.nq + 2 * a.nkv) * 128 && a.Sp % 32 == 0 && a.Sp >= 32 &&
+                                a.Mvalid > 0 && a.Mvalid % a.Sp == 0 && a.Mvalid <= a.Mpad;
     return epi == EPI_BIAS || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_SWIGLU;
 }
 
@@ -578,7 +645,7 @@ const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
     if (a.gx_rows <= 0) a.gx_rows = a.Mvalid > 0 ? a.Mvalid : a.Mpad;     // ... over the rows that exist (slack rows up to Mpad hold leftovers)
     if (!glc_gemm256x_supported(a, epi)) return "gemm256x: unsupported shape";
     if (!a.A || !a.W) return "gemm256x: null operand";
-    if (epi == EPI_QKV) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256x: null QKV output"; }
+    if (epi == EPI_QKV || epi == EPI_QKVR) { if (!a.Qh || !a.Kh || !a.Vt) return "gemm256x: null QKV output"; if (epi == EPI_QKVR && !a.rope_cs) return "gemm256x: null RoPE table"; }
     else if (!a.C) return "gemm256x: null output";
     if (epi == EPI_RESID && !a.resid) return "gemm256x: null residual";
     const int ntn = a.N / TN;
@@ -591,6 +658,17 @@ const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
             const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
             const char* m = launch_x<EPI_QKV, false>(st, a, nq, nqk - nq);
             return m ? m : launch_x<EPI_QKV, true>(st, a, nqk, ntn - nqk);
+        }
+        case EPI_QKVR: {
+            const int nqk = (a.nq + a.nkv) / 2;              // 256-column tiles of the Q and K heads; the V heads run transposed
+            static std::atomic<unsigned> lds_ok{0};
+            if (!glc_raise_lds_limit(gemm256x_qkvr_kernel, NSLOT * STAGE, lds_ok)) return "gemm256x: cannot raise the dynamic LDS limit";
+            GemmArgs b = a;
+            b.n_group = 0;
+            b.prio_mode = a.prio_mode >= 0 ? a.prio_mode : 1;
+            if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);
+            hipLaunchKernelGGL(gemm256x_qkvr_kernel, dim3((a.Mpad / TM) * ntn), dim3(512), NSLOT * STAGE, st, b, nqk, ntn);
+            return nullptr;
         }
     }
     return "gemm256x: bad epilogue";

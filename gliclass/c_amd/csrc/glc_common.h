@@ -213,6 +213,20 @@ __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const floa
         *reinterpret_cast<u32x4*>(p + 64 + (e0 & 31) * 2) = x8;
     }
 }
+// 8 consecutive values of one row of an MX tile (decoder_mx.hip; the decoder QKV epilogue of gemm256x.hip): the 16-byte f16 piece and the two
+// 8-byte fp8 pieces (hl: (hi8 | lo8), else (lo8 | hi8)); exponent 0
+__device__ __forceinline__ void store_mx8(unsigned char* f16_dst, unsigned char* mx_dst, const float (&v)[8], bool hl, unsigned* sat) {
+    gx_range_note(v, 1.0f, sat);
+    gs_h8 hi;
+    float lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const f16_t hv = (f16_t)v[j]; hi[j] = hv; lo[j] = (v[j] - (float)hv) * (float)(1 << GLC_GX_SHIFT); }
+    const u32x2 l8 = {glc_fp8x4(lo[0], lo[1], lo[2], lo[3]), glc_fp8x4(lo[4], lo[5], lo[6], lo[7])};
+    const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
+    *reinterpret_cast<gs_h8*>(f16_dst) = hi;
+    *reinterpret_cast<u32x2*>(mx_dst) = hl ? h8 : l8;
+    *reinterpret_cast<u32x2*>(mx_dst + 16) = hl ? l8 : h8;
+}
 // x = hi + lo8 * inv_lo, inv_lo = 2^-(sc + SHIFT)
 __device__ __forceinline__ void gx_decode8(const gs_h8& hi, const u32x2& lo8, float inv_lo, float (&v)[8]) {
     v[0] = (float)hi[0] + __builtin_amdgcn_cvt_f32_fp8((int)lo8[0], 0) * inv_lo; v[1] = (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8((int)lo8[0], 1) * inv_lo;

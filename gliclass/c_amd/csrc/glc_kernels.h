@@ -7,7 +7,8 @@
 
 enum { GLC_DT_F32 = 0, GLC_DT_BF16 = 1, GLC_DT_F16 = 2 };  // == GLC_F32/BF16/F16 of gliclass_hip.h
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3,
-       EPI_SWIGLU = 4 };   // gemm256s only: W rows interleave 16 gate / 16 up features; C [Mpad, N/2] = silu(gate) * up
+       EPI_SWIGLU = 4,     // gemm256s / gemm256x: W rows interleave 16 gate / 16 up features; C [Mpad, N/2] = silu(gate) * up
+       EPI_QKVR = 5 };     // gemm256x only, decoder backbone: RoPE + softmax scale + the MX tiles of decoder_mx.hip written by the epilogue (rope_cs ..)
 
 // Developer A/B switches (GLC_* environment variables: kernel variants kept for same-box comparisons) are read only by a
 // library built with -DGLC_DEVELOPER (make DEV=1); the product library reads the documented GLICLASS_* knobs and nothing else.
@@ -68,7 +69,15 @@ struct GemmArgs {
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
     unsigned* gx_sat = nullptr;             // gemm256x: fp8 range guard counter (filled by the launcher from glc_gx_sat_ptr())
     int gx_rows = 0;                        // ... counted over rows [0, gx_rows) only: the slack rows up to Mpad hold leftovers of other forwards (0: Mvalid, else Mpad)
+    // gemm256x, EPI_QKVR (decoder backbone, head_dim 128, nq and nkv even): N = (nq + 2 nkv) 128 fused projection columns; W rows (and bias)
+    // of every Q / K head in the order glc_rope_perm128 gives (the two members of a rotate-half pair in one wave's accumulators); the
+    // epilogue applies RoPE (rope_cs [Sp][64] (cos, sin)) and qscale (Q) in fp32 and writes Qh / Kh / Vt as the MX tiles of decoder_mx.hip.
+    const float* rope_cs = nullptr; float qscale = 1.f; int nq = 0, nkv = 0;
+    int perm_cols = 0;                      // gemm256x, EPI_BIAS with gs_c_plain: columns [0, perm_cols) arrive in that order and are stored at their logical place
 };
+// EPI_QKVR: physical row p (0 .. 127) of a Q / K head of the fused projection weight holds logical feature glc_rope_perm128(p): the 32-blocks
+// 1 and 2 trade places, so that a wave's 64 columns are features [32 h, 32 h + 32) and their rotate-half partners [64 + 32 h, 64 + 32 h + 32)
+__host__ __device__ inline int glc_rope_perm128(int p) { const int b = (p >> 5) & 3; return (p & 31) | ((((b & 1) << 1) | (b >> 1)) << 5); }
 // Precision-budget mask of an engine (developer, gliclass_hip.h glc_debug_set_precision_mask): a set bit rounds that operand of the
 // default mode's group-split pipeline to f16 by dropping its lo halves (numerically identical to the cheaper kernel that never
 // fetches them).  GEMM classes x (A, W); attention operand tensors; the GS residual reads of the two residual GEMMs.

@@ -261,6 +261,16 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
                 assert np.isfinite(mx).all() and not np.array_equal(mx, gs)
                 assert np.abs(sig(mx) - sig(ref)).max() <= 3e-4, (B, S)
                 assert np.abs(sig(mx) - sig(gs)).max() <= 3e-4, (B, S)
+                # dec-mini (head_dim 128, even head counts): RoPE + MX tiles are the QKV projection's epilogue (gemm256x EPI_QKVR, weight
+                # rows of every Q / K head reordered at load).  With the attention back on split units the same reordered weights go through
+                # the plain-row epilogue (columns put back in place) and the separate RoPE / layout pass: both orders, one answer.
+                assert eng.last_mx_attention()
+                eng.set_mx_attention(False)
+                mxs = eng.forward(ids, mask)
+                eng.set_mx_attention(True)
+                assert eng.last_mx() and not eng.last_mx_attention()
+                assert np.abs(sig(mxs) - sig(ref)).max() <= 3e-4, (B, S)
+                assert np.abs(sig(mxs) - sig(mx)).max() <= 3e-4, (B, S)
     finally:
         eng.close()
 

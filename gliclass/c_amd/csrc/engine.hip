@@ -1593,6 +1593,8 @@ int glc_debug_get_hidden(glc_engine* e, int which, float* out, size_t out_elems)
  * which: 0 = auto (256-tile when possible), 1 = force the 128x128 kernel.  Returns ms per launch or <0. */
 float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iters, int which) {
     // which == 6: the group-split fp32-mode kernel (rows of [32 hi | 32 lo] f16 groups, 4 bytes per element; any engine dtype)
+    const int epi_abl = which / 1000;          // which = 1000 abl + 100 (1 + prio) + 9: timing ablations of the GX-row epilogue (GemmArgs::epi_abl)
+    which %= 1000;
     const int which_in = which;
     if (which >= 100) which %= 100;
     const bool mxb = which == 9 || which == 10;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
@@ -1625,6 +1627,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         if (hipMemcpyAsync(bias, tmp, N * sizeof(float), hipMemcpyDeviceToDevice, e->stream)) break;
         GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K; g.mx_ws = mx_ws;
         if (mxb && which_in >= 100) g.prio_mode = which_in / 100 - 1;      // which = 100 (1 + prio) + 9 | 10
+        g.epi_abl = mxb ? epi_abl : 0;
         const char* m = nullptr;
         auto launch = [&]() -> const char* { return mxb ? glc_launch_gemm256x(e->stream, epi, g) : gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 5 || which == 7) ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();

@@ -442,7 +442,15 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                         float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * N + nl;
                         *reinterpret_cast<f32x4*>(cp) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, m < p.gx_rows ? p.gx_sat : nullptr);      // FFN1's intermediate: streams (non-temporal)
+                    } else
+#ifdef GLC_DEVELOPER
+                    if (p.epi_abl == 0)
+#endif
+                    gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, m < p.gx_rows ? p.gx_sat : nullptr);      // FFN1's intermediate: streams (non-temporal)
+#ifdef GLC_DEVELOPER
+                    else if (p.epi_abl == 2) gx_store8<false, true>(reinterpret_cast<unsigned char*>(p.C) + (size_t)(m & 255) * 4 * N, n, v, kHi, kLo, nullptr);      // (timing only: cache-resident target)
+                    else if (p.epi_abl == 3) gx_store8<false, false>(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * 4 * N, n, v, kHi, kLo, nullptr);      // (timing only: temporal stores)
+#endif
                 }
             }
             }
@@ -656,7 +664,7 @@ const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
         case EPI_SWIGLU: return a.bias ? "gemm256x: the SwiGLU epilogue takes no bias" : launch_x<EPI_SWIGLU, false>(st, a, 0, ntn);
         case EPI_QKV: {
             const int nqk = 2 * a.H / TN, nq = a.qkv_skip_q ? a.H / TN : 0;
-            const char* m = launch_x<EPI_QKV, false>(st, a, nq, nqk - nq);
+            const char* m = launch_x<EPI_QKV, false>(st, a, nq, nqk - nq);      // (one launch for both, as EPI_QKVR below: measured +-0 at c3 — 6 + 3 full rounds either way)
             return m ? m : launch_x<EPI_QKV, true>(st, a, nqk, ntn - nqk);
         }
         case EPI_QKVR: {

@@ -73,6 +73,7 @@ struct GemmArgs {
     // of every Q / K head in the order glc_rope_perm128 gives (the two members of a rotate-half pair in one wave's accumulators); the
     // epilogue applies RoPE (rope_cs [Sp][64] (cos, sin)) and qscale (Q) in fp32 and writes Qh / Kh / Vt as the MX tiles of decoder_mx.hip.
     const float* rope_cs = nullptr; float qscale = 1.f; int nq = 0, nkv = 0;
+    int epi_abl = 0;                        // developer timing ablations of the GX-row epilogue (glc_debug_gemm_bench): 1 = no stores, 2 = every tile stores into rows [0, 256)
     int perm_cols = 0;                      // gemm256x, EPI_BIAS with gs_c_plain: columns [0, perm_cols) arrive in that order and are stored at their logical place
 };
 // EPI_QKVR: physical row p (0 .. 127) of a Q / K head of the fused projection weight holds logical feature glc_rope_perm128(p): the 32-blocks

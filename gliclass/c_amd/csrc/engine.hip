@@ -1216,8 +1216,8 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
     // pre-norm decoder's massive-activation channels can leave the f16 range although every normalised row is tiny — so a non-finite
     // result of a folded forward is retried ONCE with the norms as kernels of their own (residual stream plain fp32, only normalised
     // rows split); what is still non-finite then fails the call.  (fp32 mode: GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native run the fp32 MFMAs.)
-    // fp8 range (round 4): the MX pipeline's operand images carry e4m3 parts with exponent 0; an activation beyond 448 saturates there and that
-    // element's cross terms fall to single-f16 accuracy without any error.  Every producer counts such elements (glc_common.h gx_range_note);
+    // fp8 range (round 4): the MX pipeline's operand images carry e4m3 parts with exponent 0; an activation beyond 448 has no image there (NaN
+    // from 464 on: the producers do not clamp, glc_common.h gx_split8).  Every producer counts such elements (glc_common.h gx_range_note);
     // a forward that counted any is repeated ONCE on the split-f16 kernels (operands up to 65504, the LayerNorm fold kept).  After kFp8Sticky
     // consecutive forwards that needed it the engine leaves the MX pipeline for good: the model has outlier channels, paying twice per forward is pointless.
     struct Restore {      // every exit path puts the engine's switches back (a HIP error inside a retry must not leave it unfused / off MX)
@@ -1237,13 +1237,7 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
         for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n && finite; ++i) finite = isfinite(logits[i]);
         const bool sat = sat_now != e->gxsat_seen;
         e->gxsat_seen = sat_now;
-        if (!finite && !tried_unfused && e->dtype == GLC_F32 && e->last_lnf) {
-            tried_unfused = true;
-            e->ln_fused = false;            // retry: norms unfused (this also leaves the MX pipeline)
-            e->range_retries++;
-            continue;
-        }
-        if (finite && sat && e->last_mx && !tried_split) {
+        if (sat && e->last_mx && !tried_split) {      // (first: beyond 464 the unclamped e4m3 parts are NaN — glc_common.h gx_split8 — so such a forward may well be non-finite)
             tried_split = true;
             e->mx = false;                  // retry: three f16 MFMAs per product, operands up to 65504
             e->fp8_retries++;
@@ -1251,6 +1245,12 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
                 e->fp8_sticky_off = true;
                 fprintf(stderr, "gliclass: activations beyond the fp8 range of the MX operand images (|x| > 448) in %d consecutive forwards; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0)\n", e->fp8_streak);
             }
+            continue;
+        }
+        if (!finite && !tried_unfused && e->dtype == GLC_F32 && e->last_lnf) {
+            tried_unfused = true;
+            e->ln_fused = false;            // retry: norms unfused (this also leaves the MX pipeline)
+            e->range_retries++;
             continue;
         }
         if (e->last_mx && !sat) e->fp8_streak = 0;

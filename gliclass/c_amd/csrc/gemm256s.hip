@@ -526,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(GemmArgs p, int n_tile
                     v[0] += bj[j][0]; v[1] += bj[j][1]; v[2] += bj[j][2]; v[3] += bj[j][3];
                     if (EPI == EPI_GELU) {
                         if constexpr (GS) {     // fp32 mode: the erf form at fp32 resolution (the 16-bit epilogue's logistic fit is only f16-exact)
-                            v[0] = glc_gelu(v[0]); v[1] = glc_gelu(v[1]); v[2] = glc_gelu(v[2]); v[3] = glc_gelu(v[3]);
+                            const f32x2 g0 = glc_gelu2_f32((f32x2){v[0], v[1]}), g1 = glc_gelu2_f32((f32x2){v[2], v[3]}); v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
                         } else {
                             const f32x2 g0 = glc_gelu2((f32x2){v[0], v[1]}), g1 = glc_gelu2((f32x2){v[2], v[3]});
                             v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];

@@ -326,7 +326,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                         }
                     }
                     v += bj[J][q];
-                    if (EPI == EPI_GELU) { v[0] = glc_gelu(v[0]); v[1] = glc_gelu(v[1]); v[2] = glc_gelu(v[2]); v[3] = glc_gelu(v[3]); }
+                    if (EPI == EPI_GELU) { const f32x2 g0 = glc_gelu2_f32((f32x2){v[0], v[1]}), g1 = glc_gelu2_f32((f32x2){v[2], v[3]}); v = (f32x4){g0[0], g0[1], g1[0], g1[1]}; }
                     *reinterpret_cast<f32x4*>(stg + c32 * 68 + 32 * J + 8 * q + 4 * h) = v;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -418,11 +418,9 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                         const int bh = b * p.nh + hh;
                         if (p.qkv_mxt) {        // MX tiles (glc_layout.h): f16 unit piece + the fp8 parts, Q as (hi8 | lo8), K as (lo8 | hi8)
                             gx_range_note(v, kHi, p.gx_sat);
-                            float lo8[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) lo8[e] = (v[e] - (float)o[e]) * kLo;
-                            const u32x2 l8 = {glc_fp8x4(lo8[0], lo8[1], lo8[2], lo8[3]), glc_fp8x4(lo8[4], lo8[5], lo8[6], lo8[7])};
-                            const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
+                            u32x2 l8, h8;
+                            gs_h8 oh;
+                            gx_split8(v, 1.0f, kInvLo, oh, l8, h8);
                             const int tile = bh * (p.Sp >> 5) + (sq >> 5), slot = which == 0 ? (sq & 31) : glc_pi32(sq & 31);
                             unsigned char* bq = reinterpret_cast<unsigned char*>(which == 0 ? p.Qh : p.Kh);
                             unsigned char* px = bq + glc_mxt_mx(tile, slot, dd);
@@ -510,11 +508,9 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                     if (p.qkv_mxt) {            // V^T MX tiles: (lo8 | hi8)
                         const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         gx_range_note(x8, kHi, p.gx_sat);
-                        float r8[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) r8[e] = (x8[e] - (float)o[e]) * kLo;
-                        const u32x2 l8 = {glc_fp8x4(r8[0], r8[1], r8[2], r8[3]), glc_fp8x4(r8[4], r8[5], r8[6], r8[7])};
-                        const u32x2 h8 = {glc_fp8x4(x8[0], x8[1], x8[2], x8[3]), glc_fp8x4(x8[4], x8[5], x8[6], x8[7])};
+                        u32x2 l8, h8;
+                        gs_h8 oh;
+                        gx_split8(x8, 1.0f, kInvLo, oh, l8, h8);
                         const int tile = (b * p.nh + hh) * (p.Sp >> 5) + (sq >> 5);
                         unsigned char* bv = reinterpret_cast<unsigned char*>(p.Vt);
                         unsigned char* px = bv + glc_mxt_v_mx(tile, dd, sq);

@@ -138,6 +138,26 @@ __device__ __forceinline__ f32x2 glc_gelu2(f32x2 x) {
     return x * r;
 }
 
+// GELU for the fp32 mode's 256-tile GEMM epilogues, two values at once, at fp32 resolution: the same form, Phi(x) = 1 / (1 + 2^(x P(x^2))), with
+// P of degree 6 in x^2 (weighted minimax fit of log2((1 - Phi) / Phi) / x on x^2 <= 36, weight d gelu / d P): |gelu - x Phi(x)| <= 6.7e-8 in
+// exact arithmetic and 5.9e-7 evaluated in fp32 over [-14, 14] (one ulp of the result near x = 5; glc_gelu's Abramowitz-Stegun form in fp32:
+// 4.6e-7).  ~6 packed VALU + 2 transcendentals per element instead of ~16 VALU + 2: the epilogue is VALU-bound
+// (profiles/r04/gemm_epilogue_ablation.txt).  x^2 clamped at 36 (P(36) = -4.98: 2^(x P) over- / underflows to the correct limits).
+__device__ __forceinline__ f32x2 glc_gelu2_f32(f32x2 x) {
+    f32x2 t = x * x;
+    t[0] = fminf(t[0], 36.0f); t[1] = fminf(t[1], 36.0f);
+    f32x2 p = t * (-5.21120420238525393e-09f) + 3.85102717598681759e-07f;
+    p = p * t + (-1.14533653638075342e-05f);
+    p = p * t + 1.59396300033220019e-04f;
+    p = p * t + 9.55694841200346347e-05f;
+    p = p * t + (-1.04838548282411514e-01f);
+    p = p * t + (-2.30220721681703733e+00f);
+    const f32x2 u = x * p;
+    f32x2 r;
+    r[0] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[0])); r[1] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u[1]));
+    return x * r;
+}
+
 // Group-split ("GS") rows of the fp32 mode (glc_kernels.h): element e of a row lives at halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
 typedef __attribute__((ext_vector_type(8))) _Float16 gs_h8;
 __device__ __forceinline__ void gs_store8(f16_t* row, int e0, const float (&v)[8]) {      // e0 % 8 == 0
@@ -156,7 +176,7 @@ __device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]
 }
 
 // "GX" rows (round 3; the operand image of the MX cross-term GEMM, gemm256x.hip): per 32 elements the same 128 bytes as a GS group, as
-//   [32 x f16 hi | 4 x (8 x fp8 lo8, 8 x fp8 hi8)],  hi = f16(x),  lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)),  hi8 = e4m3(x * 2^sc)   (saturating)
+//   [32 x f16 hi | 4 x (8 x fp8 lo8, 8 x fp8 hi8)],  hi = f16(x),  lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)),  hi8 = e4m3(x * 2^sc)   (weights: saturating; activations: see gx_split8)
 // i.e. the fp8 parts of elements 8 j .. 8 j + 7 sit together in the 16 bytes at 64 + 16 j — activations ("A order") as [lo8 | hi8],
 // weights ("W order") as [hi8 | lo8] — so a producer that holds 8 consecutive values writes two 16-byte pieces, like a GS row.
 // A split product a*w = a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) keeps its f16 MFMA for the first term and runs BOTH cross terms as ONE
@@ -166,7 +186,7 @@ __device__ __forceinline__ void gs_load8(const f16_t* row, int e0, float (&v)[8]
 // are ~2^-11 of the product, so their 4-bit operands leave a relative error of ~2^-15 — sixteen times below single f16 operands — at
 // 2 instead of 3 f16-MFMA times per product.  x = hi + lo8 * 2^-(SHIFT + sc) also reads a row back to ~15 bits (residual adds, row
 // gathers).  SHIFT = 11: |lo| <= 2^-11 |hi|, so the scaled residual never exceeds |hi| and shares hi8's range; what leaves that range
-// (|x| 2^sc > 448) saturates, i.e. such an element falls back towards single-f16 precision instead of overflowing.
+// (|x| 2^sc > 448) is counted by the fp8 range guard below and that forward is repeated on the split-f16 kernels.
 #ifndef GLC_GX_SHIFT
 #define GLC_GX_SHIFT 11
 #endif
@@ -177,9 +197,8 @@ __device__ __forceinline__ uint32_t glc_fp8x4(float a, float b, float c, float d
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (uint32_t)w;
 }
-// fp8 range guard.  An activation beyond the e4m3 range (|x| 2^sc > 448) saturates in its fp8 parts: its cross terms — and the lo8 part a
-// residual read-back adds to hi — are then wrong by up to 2^-11 of the element, i.e. that element falls to single-f16 accuracy without any
-// error being raised.  Synthetic weights never get there; the outlier channels of trained checkpoints (10^2 .. 10^4 in the raw residual
+// fp8 range guard.  An activation beyond the e4m3 range (|x| 2^sc > 448) has no e4m3 image (the unclamped conversion of gx_split8 gives
+// 448 up to 464 and NaN beyond; a clamped one would silently leave that element at single-f16 accuracy).  Synthetic weights never get there; the outlier channels of trained checkpoints (10^2 .. 10^4 in the raw residual
 // stream of a pre-norm decoder) do.  Every producer of an activation operand image (GX rows, MX tiles) therefore counts such elements
 // in a per-engine device counter (sat != nullptr); the engine reads it with the logits and repeats a forward that counted any on the
 // split-f16 kernels, whose operands hold up to 65504 (engine.hip forward_one).
@@ -191,6 +210,27 @@ __device__ __forceinline__ void gx_range_note(const float (&v)[8], float k_hi, u
     m = fmaxf(m, fabsf(v[7]));
     if (m * k_hi > 448.0f) atomicAdd(sat, 1u);
 }
+// The activation split of 8 values: hi = f16(x) (RNE), lo8 = e4m3((x - hi) / inv_lo), hi8 = e4m3(x / inv_hi), inv_* powers of two (the
+// conversion takes the divisor as a scale operand: no multiply).  Runs once per element in every GEMM epilogue, where it IS the epilogue's
+// time (profiles/r04/gemm_epilogue_ablation.txt), so it does NOT clamp: a value beyond e4m3's range (|x / inv_hi| > 448, NaN from 464 on)
+// has been counted by the fp8 range guard at the same call site (gx_range_note) and the result of that forward is never used (engine.hip
+// forward_one / glc_engine_sync).  Weights and tables (converted once, no guard) keep the saturating glc_fp8x4.
+__device__ __forceinline__ void gx_split8(const float (&v)[8], float inv_hi, float inv_lo, gs_h8& hi, u32x2& l8, u32x2& h8) {
+    typedef short v2i16 __attribute__((ext_vector_type(2)));
+    float l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; l[e] = v[e] - (float)h; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        v2i16 wl = {0, 0}, wh = {0, 0};
+        wl = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl, l[4 * q], l[4 * q + 1], inv_lo, false);
+        wl = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl, l[4 * q + 2], l[4 * q + 3], inv_lo, true);
+        wh = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wh, v[4 * q], v[4 * q + 1], inv_hi, false);
+        wh = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wh, v[4 * q + 2], v[4 * q + 3], inv_hi, true);
+        l8[q] = __builtin_bit_cast(uint32_t, wl);
+        h8[q] = __builtin_bit_cast(uint32_t, wh);
+    }
+}
 // eight consecutive elements e0 .. e0 + 7 (e0 % 8 == 0) of a GX row; `row` = the row's first byte; k_hi = 2^sc, k_lo = 2^(sc + SHIFT)
 // NT: non-temporal stores — for an output that streams to HBM and is too large for the caches to keep until its reader runs (FFN1's 805 MB
 // intermediate at c3): it then does not evict the operand panels the same launch is still re-reading (FFN1 + GELU 750 -> 717 us).
@@ -198,13 +238,20 @@ template <bool WORDER = false, bool NT = false>
 __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const float (&v)[8], float k_hi, float k_lo, unsigned* sat = nullptr) {
     gx_range_note(v, k_hi, sat);
     gs_h8 hi;
-    float l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; l[e] = (v[e] - (float)h) * k_lo; }
     unsigned char* p = row + (e0 >> 5) * 128;
-    const uint32_t l0 = glc_fp8x4(l[0], l[1], l[2], l[3]), l1 = glc_fp8x4(l[4], l[5], l[6], l[7]);
-    const uint32_t h0 = glc_fp8x4(v[0] * k_hi, v[1] * k_hi, v[2] * k_hi, v[3] * k_hi), h1 = glc_fp8x4(v[4] * k_hi, v[5] * k_hi, v[6] * k_hi, v[7] * k_hi);
-    const u32x4 x8 = WORDER ? (u32x4){h0, h1, l0, l1} : (u32x4){l0, l1, h0, h1};
+    u32x4 x8;
+    if constexpr (WORDER) {          // weights, once at load: saturating
+        float l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const f16_t h = (f16_t)v[e]; hi[e] = h; l[e] = (v[e] - (float)h) * k_lo; }
+        const uint32_t l0 = glc_fp8x4(l[0], l[1], l[2], l[3]), l1 = glc_fp8x4(l[4], l[5], l[6], l[7]);
+        const uint32_t h0 = glc_fp8x4(v[0] * k_hi, v[1] * k_hi, v[2] * k_hi, v[3] * k_hi), h1 = glc_fp8x4(v[4] * k_hi, v[5] * k_hi, v[6] * k_hi, v[7] * k_hi);
+        x8 = (u32x4){h0, h1, l0, l1};
+    } else {                         // activations, every forward: gx_split8 (k_hi, k_lo powers of two: their reciprocals are exact)
+        u32x2 l8, h8;
+        gx_split8(v, 1.0f / k_hi, 1.0f / k_lo, hi, l8, h8);
+        x8 = (u32x4){l8[0], l8[1], h8[0], h8[1]};
+    }
     if constexpr (NT) {
         __builtin_nontemporal_store(__builtin_bit_cast(u32x4, hi), reinterpret_cast<u32x4*>(p + (e0 & 31) * 2));
         __builtin_nontemporal_store(x8, reinterpret_cast<u32x4*>(p + 64 + (e0 & 31) * 2));
@@ -218,11 +265,8 @@ __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const floa
 __device__ __forceinline__ void store_mx8(unsigned char* f16_dst, unsigned char* mx_dst, const float (&v)[8], bool hl, unsigned* sat) {
     gx_range_note(v, 1.0f, sat);
     gs_h8 hi;
-    float lo[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const f16_t hv = (f16_t)v[j]; hi[j] = hv; lo[j] = (v[j] - (float)hv) * (float)(1 << GLC_GX_SHIFT); }
-    const u32x2 l8 = {glc_fp8x4(lo[0], lo[1], lo[2], lo[3]), glc_fp8x4(lo[4], lo[5], lo[6], lo[7])};
-    const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
+    u32x2 l8, h8;
+    gx_split8(v, 1.0f, 1.0f / (float)(1 << GLC_GX_SHIFT), hi, l8, h8);
     *reinterpret_cast<gs_h8*>(f16_dst) = hi;
     *reinterpret_cast<u32x2*>(mx_dst) = hl ? h8 : l8;
     *reinterpret_cast<u32x2*>(mx_dst + 16) = hl ? l8 : h8;

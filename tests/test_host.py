@@ -403,3 +403,29 @@ def test_effective_cpus_respects_affinity_and_env(monkeypatch):
     assert hostinfo.effective_cpus() == 1
     monkeypatch.setenv("OMP_NUM_THREADS", "100000")
     assert hostinfo.effective_cpus() == n or hostinfo.effective_cpus() <= (os.cpu_count() or 1)
+
+
+def test_gelu_logit_fit_of_the_gemm_epilogue_is_fp32_exact():
+    """The 256-tile GEMM epilogues of the fp32 mode compute GELU as x / (1 + 2^(x P(x^2))) (csrc/glc_common.h glc_gelu2_f32; HF
+    ACT2FN["gelu"] = 0.5 x (1 + erf(x / sqrt 2)), modeling_deberta_v2.py:393).  The constants are read from the header and the formula is
+    evaluated here in float32, operation by operation: it must stay within one fp32 ulp-class distance (7e-7) of the erf form over the
+    whole range, including the clamp at x^2 = 36 and the far tails."""
+    from scipy.special import erfc
+    src = open(os.path.join(ROOT, "gliclass", "c_amd", "csrc", "glc_common.h")).read()
+    body = src[src.index("f32x2 glc_gelu2_f32("):]
+    body = body[:body.index("return x * r;")]
+    c = [float(m) for m in re.findall(r"\(?(-?\d\.\d+e[+-]\d+)f\)?", body)]
+    assert len(c) == 7 and "36.0f" in body
+    f = np.float32
+    xs = np.concatenate([np.linspace(-14, 14, 700001), np.linspace(-60, 60, 1201), [0.0, -0.0, 5.9999, 6.0, 6.0001, -6.0]]).astype(f)
+    t = np.minimum(xs * xs, f(36.0))
+    p = (t * f(c[0]) + f(c[1])).astype(f)
+    for k in c[2:]:
+        p = (p * t + f(k)).astype(f)
+    with np.errstate(over="ignore"):
+        g = (xs * (f(1.0) / (f(1.0) + np.exp2((xs * p).astype(f)).astype(f))).astype(f)).astype(f)
+    x64 = xs.astype(np.float64)
+    ref = x64 * 0.5 * erfc(-x64 / np.sqrt(2.0))
+    assert np.isfinite(g).all()
+    assert np.abs(g - ref).max() <= 7e-7, np.abs(g - ref).max()
+    assert np.abs(g - ref)[np.abs(x64) <= 1.0].max() <= 1.5e-7

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx2_kernel(AttnArgs a) {
                 v[e] = h ? got : own_a;
                 v[4 + e] = h ? own_b : got;
             }
-            gx_store8(row, col0 + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), a.gx_sat);
+            gx_store8(row, col0 + 16 * p + 8 * h, v, gx_act_khi(a.act_sc), gx_act_klo(a.act_sc), a.gx_sat);
         }
     };
     store_gx(o0, 64 * hh);
@@ -566,6 +566,7 @@ bool glc_mx2_build_tables(int Sp, int P, const int32_t* dtab, std::vector<unsign
 const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a_in) {
     AttnArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the GX context rows
+    if (!a.act_sc) a.act_sc = glc_gx_act_sc();               // ... and the exponent of the activation rows (engine.hip act_sc)
     if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.idx16 || !a.tinfo) return "attention(mx2): null pointer";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx2): bad shape";
     if (a.sel_b || a.tile_flag) return "attention(mx2): no row selection in this kernel";

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_wg_kernel(AttnArgs a) {
                     v[e] = h ? got : own_a;           // h = 0: columns 16p + e (own), 16p + 4 + e (partner);  h = 1: 16p + 8 + e (partner), 16p + 12 + e (own)
                     v[4 + e] = h ? own_b : got;
                 }
-                gx_store8(row, col0 + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), a.gx_sat);
+                gx_store8(row, col0 + 16 * p + 8 * h, v, gx_act_khi(a.act_sc), gx_act_klo(a.act_sc), a.gx_sat);
             }
         };
         store_gx(o0, 64 * hh);
@@ -596,6 +596,7 @@ template <typename T, bool SPLIT, int NW, bool KVG, bool STAG = false, bool VGL 
 const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a_in) {
     AttnArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the GX context rows (ctx_gs == 2)
+    if (!a.act_sc) a.act_sc = glc_gx_act_sc();               // ... and the exponent of the activation rows (engine.hip act_sc)
     if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(wg): null pointer";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(wg): bad shape";
     if (a.sel_b) return "attention(wg): no row selection in this kernel";

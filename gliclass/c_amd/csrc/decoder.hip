@@ -387,7 +387,7 @@ template <typename T, int D, bool SPLIT = false>
 __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const T* __restrict__ Qf, const T* __restrict__ Kf, const T* __restrict__ Vt,
                                                                const float* __restrict__ kbias, const int* __restrict__ klen,
                                                                const int* __restrict__ kfirst_, T* __restrict__ CTX, int B, int Sp, int nq,
-                                                               int nkv, int causal, int ctx_gs, unsigned* gx_sat) {
+                                                               int nkv, int causal, int ctx_gs, unsigned* gx_sat, int act_sc) {
     static_assert(!SPLIT || sizeof(T) == 4, "split units live in the fp32 layouts");
     typedef typename GqaFrag<SPLIT, T>::type frag_t;
     constexpr int NS = D / 16, ND = D / 32;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, SPLIT ? 1 : 2) void attn_gqa_mfma_kernel(const
                     v[e] = h ? got : own_a;
                     v[4 + e] = h ? own_b : got;
                 }
-                gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), gx_sat);
+                gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, gx_act_khi(act_sc), gx_act_klo(act_sc), gx_sat);
             }
     } else if (ctx_gs) {
         // group-split context rows: block a of this head is group hq * D/32 + a of the row; hi = f16(v), lo = f16(v - hi)
@@ -559,8 +559,8 @@ template <typename T, bool SPLIT = false> const char* launch_gqa_t(hipStream_t s
                                                const int* kfirst, void* CTX, int B, int Sp, int nq, int nkv, int d, int causal, int ctx_gs = 0) {
     const int nt = Sp / 32, nqb = (nt + 3) / 4, per = (nq / nkv) * nqb, bg8 = (B * nkv + 7) / 8 * 8;
     const dim3 grid(per * bg8), block(256);
-    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal, ctx_gs, ctx_gs == 2 ? glc_gx_sat_ptr() : nullptr);
-    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal, ctx_gs, ctx_gs == 2 ? glc_gx_sat_ptr() : nullptr);
+    if (d == 128) hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 128, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal, ctx_gs, ctx_gs == 2 ? glc_gx_sat_ptr() : nullptr, glc_gx_act_sc());
+    else hipLaunchKernelGGL((attn_gqa_mfma_kernel<T, 64, SPLIT>), grid, block, 0, st, (const T*)Qf, (const T*)Kf, (const T*)Vt, kbias, klen, kfirst, (T*)CTX, B, Sp, nq, nkv, causal, ctx_gs, ctx_gs == 2 ? glc_gx_sat_ptr() : nullptr, glc_gx_act_sc());
     return nullptr;
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void qkv_layout_mx_kernel(const float* __restr
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_gqa_mx_kernel(const unsigned char* __restrict__ Qm, const unsigned char* __restrict__ Km, const unsigned char* __restrict__ Vm,
                                                              const float* __restrict__ kbias, const int* __restrict__ klen, const int* __restrict__ kfirst_,
-                                                             unsigned char* __restrict__ CTX, int B, int Sp, int nq, int nkv, int causal, unsigned* gx_sat) {
+                                                             unsigned char* __restrict__ CTX, int B, int Sp, int nq, int nkv, int causal, unsigned* gx_sat, int act_sc) {
     constexpr int NS = D / 16, NM = D / 32, ND = D / 32, TILE = 32 * D * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mx_kernel(const unsigned char
                 v[e] = h ? got : own_a;
                 v[4 + e] = h ? own_b : got;
             }
-            gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), gx_sat);
+            gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, gx_act_khi(act_sc), gx_act_klo(act_sc), gx_sat);
         }
 }
 
@@ -269,7 +269,7 @@ __device__ __forceinline__ void glds16_sv(const unsigned char* ubase, unsigned l
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_gqa_mx_ring_kernel(const unsigned char* __restrict__ Qm, const unsigned char* __restrict__ Km, const unsigned char* __restrict__ Vm,
                                                                   const float* __restrict__ kbias, const int* __restrict__ klen, const int* __restrict__ kfirst_,
-                                                                  unsigned char* __restrict__ CTX, int B, int Sp, int nq, int nkv, int causal, unsigned* gx_sat) {
+                                                                  unsigned char* __restrict__ CTX, int B, int Sp, int nq, int nkv, int causal, unsigned* gx_sat, int act_sc) {
     constexpr int NS = D / 16, NM = D / 32, ND = D / 32, TILE = 32 * D * 4, P4 = D / 32;      // P4: one-KiB pieces per wave and tile of K (and of V^T)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_gqa_mx_ring_kernel(const unsigned
                 v[e] = h ? got : own_a;
                 v[4 + e] = h ? own_b : got;
             }
-            gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, 1.0f, (float)(1 << GLC_GX_SHIFT), gx_sat);
+            gx_store8(row, hq * D + 32 * a + 16 * p + 8 * h, v, gx_act_khi(act_sc), gx_act_klo(act_sc), gx_sat);
         }
 }
 
@@ -504,14 +504,14 @@ const char* glc_launch_attention_gqa_mx(hipStream_t st, const void* Qm, const vo
         static std::atomic<unsigned> ok128{0}, ok64{0};
         if (d == 128) {
             if (!glc_raise_lds_limit(attn_gqa_mx_ring_kernel<128>, (int)lds, ok128)) return "attention_gqa_mx: cannot raise the dynamic LDS limit";
-            hipLaunchKernelGGL(attn_gqa_mx_ring_kernel<128>, grid, block, lds, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
+            hipLaunchKernelGGL(attn_gqa_mx_ring_kernel<128>, grid, block, lds, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat, glc_gx_act_sc());
         } else {
             if (!glc_raise_lds_limit(attn_gqa_mx_ring_kernel<64>, (int)lds, ok64)) return "attention_gqa_mx: cannot raise the dynamic LDS limit";
-            hipLaunchKernelGGL(attn_gqa_mx_ring_kernel<64>, grid, block, lds, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
+            hipLaunchKernelGGL(attn_gqa_mx_ring_kernel<64>, grid, block, lds, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat, glc_gx_act_sc());
         }
         return nullptr;
     }
-    if (d == 128) hipLaunchKernelGGL(attn_gqa_mx_kernel<128>, grid, block, 0, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
-    else hipLaunchKernelGGL(attn_gqa_mx_kernel<64>, grid, block, 0, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat);
+    if (d == 128) hipLaunchKernelGGL(attn_gqa_mx_kernel<128>, grid, block, 0, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat, glc_gx_act_sc());
+    else hipLaunchKernelGGL(attn_gqa_mx_kernel<64>, grid, block, 0, st, (const unsigned char*)Qm, (const unsigned char*)Km, (const unsigned char*)Vm, kbias, klen, kfirst, (unsigned char*)CTX, B, Sp, nq, nkv, causal, sat, glc_gx_act_sc());
     return nullptr;
 }

@@ -101,6 +101,11 @@ struct glc_engine {
     // any; consecutive such forwards (the model has outlier channels: after kFp8Sticky of them the engine leaves the MX pipeline for good)
     unsigned* d_gxsat = nullptr; unsigned gxsat_seen = 0; unsigned* h_gxsat = nullptr;
     int fp8_retries = 0, fp8_streak = 0; bool fp8_sticky_off = false, fp8_device_pending = false;
+    // Activation exponent of the MX pipeline's GX rows (hi8 = e4m3(x 2^act_sc), glc_common.h): 0 until a forward leaves the e4m3 range (|x| > 448);
+    // the guard's FIRST answer is then kActScLow = -5 for this engine (rows hold |x| up to 14336, elements below 0.5 keep fewer hi8 bits — their
+    // cross terms are 2^-16 of a unit product either way) and the forward is repeated on the MX pipeline; only what still leaves the range
+    // (or an MX tile of the attention: Q, K, V, P keep exponent 0) goes to the split-f16 kernels.
+    int act_sc = 0;
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;     // fp32 partial tiles of the split-K GEMM path (small M)
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -144,6 +149,13 @@ struct glc_engine {
 };
 
 namespace {
+
+constexpr int kActScLow = -5;
+// the launchers' view of the engine for one forward (glc_kernels.h): fp8 guard counter and activation exponent, reset behind it
+struct GxScope {
+    explicit GxScope(glc_engine* e) { glc_gx_sat_ptr() = e->d_gxsat; glc_gx_act_sc() = e->act_sc; }
+    ~GxScope() { glc_gx_sat_ptr() = nullptr; glc_gx_act_sc() = 0; }
+};
 
 void* dmalloc(glc_engine* e, size_t bytes, bool zero = true) {
     void* p = nullptr;
@@ -525,7 +537,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     const size_t es = esize(dt);
     const int ccap = e->capC > 0 ? e->capC : 1;
     if (e->profile) { e->ev_used = 0; }
-    glc_gx_sat_ptr() = e->d_gxsat;           // fp8 range guard: the launchers of this thread hand the counter to every producer of GX rows / MX tiles
+    GxScope gx_scope(e);                     // fp8 range guard + activation exponent: the launchers of this thread hand them to every producer / reader of GX rows and MX tiles
     if (e->keep_hidden) {
         const size_t need = (size_t)(L + 1) * M * H * es;
         if (need > e->hidden_cap) { dfree(e, e->hidden_dump); e->hidden_dump = dmalloc(e, need); if (!e->hidden_dump) return false; e->hidden_cap = need; }
@@ -654,7 +666,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     const size_t es = esize(dt);
     const int ccap = e->capC > 0 ? e->capC : 1;
     if (e->profile) { e->ev_used = 0; }
-    glc_gx_sat_ptr() = e->d_gxsat;           // fp8 range guard (see run_forward_decoder)
+    GxScope gx_scope(e);                     // fp8 range guard + activation exponent (see run_forward_decoder)
 
     if (e->keep_hidden) {
         const size_t need = (size_t)(c.layers + 1) * M * H * es;
@@ -1226,8 +1238,8 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
     } restore{e, e->ln_fused, e->mx};
     if (e->fp8_sticky_off) e->mx = false;
     unsigned sat_now = e->gxsat_seen;
-    bool tried_unfused = false, tried_split = false;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    bool tried_unfused = false, tried_split = false, tried_low = false;
+    for (int attempt = 0; attempt < 4; ++attempt) {      // at most: MX, MX with exponent kActScLow, split-f16, norms unfused
         if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) return -1;
         HIPCHK(hipMemcpyAsync(cnt, e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
         if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
@@ -1237,7 +1249,14 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
         for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n && finite; ++i) finite = isfinite(logits[i]);
         const bool sat = sat_now != e->gxsat_seen;
         e->gxsat_seen = sat_now;
-        if (sat && e->last_mx && !tried_split) {      // (first: beyond 464 the unclamped e4m3 parts are NaN — glc_common.h gx_split8 — so such a forward may well be non-finite)
+        if (sat && e->last_mx && e->act_sc == 0 && !tried_low) {      // first answer: activation rows with exponent kActScLow, still on the MX pipeline (kept for this engine)
+            tried_low = true;
+            e->act_sc = kActScLow;
+            e->fp8_retries++;
+            fprintf(stderr, "gliclass: activations beyond the fp8 range of the MX operand images (|x| > 448); this engine's activation rows now carry exponent %d (|x| up to %d)\n", kActScLow, 448 << -kActScLow);
+            continue;
+        }
+        if (sat && e->last_mx && !tried_split) {      // (before the non-finite check: beyond 464 the unclamped e4m3 parts are NaN — glc_common.h gx_split8 — so such a forward may well be non-finite)
             tried_split = true;
             e->mx = false;                  // retry: three f16 MFMAs per product, operands up to 65504
             e->fp8_retries++;
@@ -1393,6 +1412,7 @@ int glc_debug_last_forward_groups(const glc_engine* e) { return e ? e->last_grou
 int glc_debug_range_retries(const glc_engine* e) { return e ? e->range_retries : -1; }
 int glc_debug_fp8_range_retries(const glc_engine* e) { return e ? e->fp8_retries : -1; }
 int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_off ? 1 : 0) : -1; }
+int glc_debug_activation_exponent(const glc_engine* e) { return e ? e->act_sc : 1; }
 long long glc_debug_mx_weight_bytes(const glc_engine* e) { return e ? (long long)e->mx_bytes : -1; }
 int glc_debug_set_mx2(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx2 = on != 0; return 0; }
 
@@ -1429,9 +1449,15 @@ int glc_engine_sync(glc_engine* e) {
         e->fp8_device_pending = false;
         if (*e->h_gxsat != e->gxsat_seen) {
             e->gxsat_seen = *e->h_gxsat;
-            e->fp8_sticky_off = true;
-            set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images (|x| > 448): its logits are at "
-                    "single-f16 accuracy in those elements; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0) — run the forward again");
+            if (e->act_sc == 0) {
+                e->act_sc = kActScLow;
+                set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images (|x| > 448): its logits are "
+                        "not valid; this engine's activation rows now carry exponent -5 (|x| up to 14336) — run the forward again");
+            } else {
+                e->fp8_sticky_off = true;
+                set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images: its logits are "
+                        "not valid; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0) — run the forward again");
+            }
             return -1;
         }
     }
@@ -1504,7 +1530,7 @@ int glc_debug_set_mx(glc_engine* e, int on) {
     if (on && !e->mx_built) { set_err("set_mx: the MX pipeline is not available to this engine (shapes, dtype, or GLICLASS_MX=0 at creation)"); return -1; }
     std::lock_guard<std::mutex> lk(e->mu);
     e->mx = on != 0;
-    if (on) { e->fp8_sticky_off = false; e->fp8_streak = 0; }      // (a developer switching MX back on also clears the range guard's verdict)
+    if (on) { e->fp8_sticky_off = false; e->fp8_streak = 0; e->act_sc = 0; }      // (a developer switching MX back on also clears the range guard's verdict)
     return 0;
 }
 int glc_debug_last_forward_mx(const glc_engine* e) { return e ? (e->last_mx ? 1 : 0) : -1; }
@@ -1538,7 +1564,7 @@ int glc_debug_read_workspace(glc_engine* e, int which, int rows, float* out) {
                 const unsigned char b = g[64 + 16 * ((c & 31) >> 3) + (c & 7)];
                 const int sg = b >> 7, ex = (b >> 3) & 15, mn = b & 7;
                 const float l8 = ex == 0 ? ldexpf((float)mn, -9) : ldexpf(1.0f + mn / 8.0f, ex - 7);
-                v += (sg ? -l8 : l8) * ldexpf(1.0f, -GLC_GX_SHIFT);
+                v += (sg ? -l8 : l8) * ldexpf(1.0f, -GLC_GX_SHIFT - e->act_sc);
             } else { memcpy(&lo, g + 64 + 2 * (c & 31), 2); v += (float)lo; }
             out[(size_t)r * W + c] = v;
         }

@@ -114,7 +114,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     const int ck0 = ((0 + h) ^ hsw) * 16, ck1 = ((2 + h) ^ hsw) * 16;       // f16 k-steps 0 / 1: logical chunks h / 2 + h
     const int cx0 = ((4 + 2 * h) ^ hsw) * 16, cx1 = ((5 + 2 * h) ^ hsw) * 16;       // the fp8 parts of elements 16 h .. 16 h + 7 / + 8 .. + 15
     // e8m0 scales (one per operand, every block): A rows (activations, exponent 0) carry the 2^-SHIFT, W rows their 2^-ws
-    const int sc_a = 127 - GLC_GX_SHIFT;
+    const int sc_a = 127 - GLC_GX_SHIFT - p.act_sc;        // e8m0 scale of the A blocks: 2^-(SHIFT + sc) (glc_common.h)
     const int sc_w = 127 - p.mx_ws;
 
     unsigned long long seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, t_loop1 = 0;
@@ -231,7 +231,8 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     const float* __restrict__ bias = p.bias;
     float* stg = reinterpret_cast<float*>(smem256x + wave * EPI_PATCH);
     const int qkv_b0 = (EPI == EPI_QKV || EPI == EPI_QKVR) ? m0 / p.Sp : 0;
-    constexpr float kHi = 1.0f, kLo = (float)(1 << GLC_GX_SHIFT), kInvLo = 1.0f / (float)(1 << GLC_GX_SHIFT);       // activation rows: exponent 0
+    const float kHi = gx_act_khi(p.act_sc), kLo = gx_act_klo(p.act_sc), kInvLo = gx_pow2_inv(kLo);       // activation rows in and out: exponent act_sc
+    constexpr float kInvLo0 = 1.0f / (float)(1 << GLC_GX_SHIFT);                                          // MX tiles (attention operands): exponent 0       // activation rows: exponent 0
     if constexpr (EPI == EPI_SWIGLU) {
         // W rows alternate 16 gate / 16 up features (engine.hip interleaves them at load): in D[n = 32 J + 8 q + 4 h + e][m] the register quads
         // q = 0, 1 hold gate features 8 q + 4 h + e of block J and q + 2 the matching up features — same lane, no exchange.  The wave's
@@ -417,10 +418,10 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                         const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;
                         const int bh = b * p.nh + hh;
                         if (p.qkv_mxt) {        // MX tiles (glc_layout.h): f16 unit piece + the fp8 parts, Q as (hi8 | lo8), K as (lo8 | hi8)
-                            gx_range_note(v, kHi, p.gx_sat);
+                            gx_range_note(v, 1.0f, p.gx_sat);
                             u32x2 l8, h8;
                             gs_h8 oh;
-                            gx_split8(v, 1.0f, kInvLo, oh, l8, h8);
+                            gx_split8(v, 1.0f, kInvLo0, oh, l8, h8);
                             const int tile = bh * (p.Sp >> 5) + (sq >> 5), slot = which == 0 ? (sq & 31) : glc_pi32(sq & 31);
                             unsigned char* bq = reinterpret_cast<unsigned char*>(which == 0 ? p.Qh : p.Kh);
                             unsigned char* px = bq + glc_mxt_mx(tile, slot, dd);
@@ -507,10 +508,10 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                     }
                     if (p.qkv_mxt) {            // V^T MX tiles: (lo8 | hi8)
                         const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        gx_range_note(x8, kHi, p.gx_sat);
+                        gx_range_note(x8, 1.0f, p.gx_sat);
                         u32x2 l8, h8;
                         gs_h8 oh;
-                        gx_split8(x8, 1.0f, kInvLo, oh, l8, h8);
+                        gx_split8(x8, 1.0f, kInvLo0, oh, l8, h8);
                         const int tile = (b * p.nh + hh) * (p.Sp >> 5) + (sq >> 5);
                         unsigned char* bv = reinterpret_cast<unsigned char*>(p.Vt);
                         unsigned char* px = bv + glc_mxt_v_mx(tile, dd, sq);
@@ -646,6 +647,7 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
     GemmArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the activation images this launch writes
+    if (!a.act_sc) a.act_sc = glc_gx_act_sc();               // ... and the exponent of the activation rows (engine.hip act_sc)
     if (a.gx_rows <= 0) a.gx_rows = a.Mvalid > 0 ? a.Mvalid : a.Mpad;     // ... over the rows that exist (slack rows up to Mpad hold leftovers)
     if (!glc_gemm256x_supported(a, epi)) return "gemm256x: unsupported shape";
     if (!a.A || !a.W) return "gemm256x: null operand";

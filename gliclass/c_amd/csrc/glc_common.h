@@ -210,6 +210,11 @@ __device__ __forceinline__ void gx_range_note(const float (&v)[8], float k_hi, u
     m = fmaxf(m, fabsf(v[7]));
     if (m * k_hi > 448.0f) atomicAdd(sat, 1u);
 }
+// 1 / k for k = 2^e (bit pattern (e + 127) << 23 -> (127 - e) << 23): the scales of the activation images are powers of two held in scalar registers
+__device__ __forceinline__ float gx_pow2_inv(float k) { return __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(uint32_t, k)); }
+// Activation images with exponent sc (engine.hip act_sc; 0 unless a forward left the e4m3 range): k_hi = 2^sc, k_lo = 2^(sc + SHIFT)
+__device__ __forceinline__ float gx_act_khi(int sc) { return __builtin_bit_cast(float, (uint32_t)(127 + sc) << 23); }
+__device__ __forceinline__ float gx_act_klo(int sc) { return __builtin_bit_cast(float, (uint32_t)(127 + sc + GLC_GX_SHIFT) << 23); }
 // The activation split of 8 values: hi = f16(x) (RNE), lo8 = e4m3((x - hi) / inv_lo), hi8 = e4m3(x / inv_hi), inv_* powers of two (the
 // conversion takes the divisor as a scale operand: no multiply).  Runs once per element in every GEMM epilogue, where it IS the epilogue's
 // time (profiles/r04/gemm_epilogue_ablation.txt), so it does NOT clamp: a value beyond e4m3's range (|x / inv_hi| > 448, NaN from 464 on)
@@ -249,7 +254,7 @@ __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const floa
         x8 = (u32x4){h0, h1, l0, l1};
     } else {                         // activations, every forward: gx_split8 (k_hi, k_lo powers of two: their reciprocals are exact)
         u32x2 l8, h8;
-        gx_split8(v, 1.0f / k_hi, 1.0f / k_lo, hi, l8, h8);
+        gx_split8(v, gx_pow2_inv(k_hi), gx_pow2_inv(k_lo), hi, l8, h8);
         x8 = (u32x4){l8[0], l8[1], h8[0], h8[1]};
     }
     if constexpr (NT) {

@@ -25,6 +25,9 @@ inline const char* glc_dev_env(const char* name) {
 // fp8 range guard (glc_common.h gx_range_note): the device counter the launchers of this host thread hand to every kernel that writes
 // activation operand images (GX rows, MX tiles).  Set by the engine around its launch sequence (under its lock); null = no counting.
 inline unsigned*& glc_gx_sat_ptr() { static thread_local unsigned* p = nullptr; return p; }
+// ... and the exponent of the activation GX rows (hi8 = e4m3(x 2^sc), glc_common.h) those launchers write and read: 0 unless the engine has lowered
+// it after a forward left the e4m3 range (engine.hip act_sc).  Both are set for the duration of one engine forward and reset behind it.
+inline int& glc_gx_act_sc() { static thread_local int sc = 0; return sc; }
 
 struct GemmArgs {
     const void* A = nullptr;      // [Mpad, K]  T
@@ -68,6 +71,7 @@ struct GemmArgs {
     int qkv_mxt = 0;                        // gemm256x, EPI_QKV: write Q / K / V^T as MX tiles (glc_layout.h) for attention_mx.hip instead of split-f16 units
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
     unsigned* gx_sat = nullptr;             // gemm256x: fp8 range guard counter (filled by the launcher from glc_gx_sat_ptr())
+    int act_sc = 0;                         // gemm256x: exponent of the ACTIVATION GX rows it reads (A, resid) and writes (C); 0 unless the engine lowered it (engine.hip act_sc)
     int gx_rows = 0;                        // ... counted over rows [0, gx_rows) only: the slack rows up to Mpad hold leftovers of other forwards (0: Mvalid, else Mpad)
     // gemm256x, EPI_QKVR (decoder backbone, head_dim 128, nq and nkv even): N = (nq + 2 nkv) 128 fused projection columns; W rows (and bias)
     // of every Q / K head in the order glc_rope_perm128 gives (the two members of a rotate-half pair in one wave's accumulators); the
@@ -177,6 +181,7 @@ struct AttnArgs {
     int prec = 0;                                     // workgroup-shared kernel, split units: (engine mask >> 8) & 63 — bits Q, K, V, P, PQ, PK rounded to f16
     const void* idx16 = nullptr; const int4* tinfo = nullptr;   // attention_mx2.hip: the tables of glc_mx2_build_tables for this Sp
     unsigned* gx_sat = nullptr;                       // GX context rows: fp8 range guard counter (filled by the launchers from glc_gx_sat_ptr())
+    int act_sc = 0;                                   // GX context rows: exponent of the activation images (engine.hip act_sc)
 };
 // impl: 1 = simple (any T), 2 = MFMA band kernel, one independent wave per 32-query tile (attention.hip)
 const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const AttnArgs& a);

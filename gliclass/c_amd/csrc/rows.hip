@@ -61,17 +61,17 @@ __device__ __forceinline__ void ln_row_wave(const T* __restrict__ x, T* __restri
 // halves (e >> 5) * 64 + (e & 31) (hi) and + 32 (lo).
 // LayerNorm of one fp32 row by one wave, output in the GS format (8 elements per lane and chunk)
 // (GX = true: the same 128-byte groups as GX rows — [32 hi | 32 lo8 | 32 hi8], glc_common.h — for the MX cross-term GEMM; activation exponent 0)
-template <bool GX> __device__ __forceinline__ void row_store8(f16_t* y, int e0, const float (&v)[8], unsigned* sat = nullptr) {
-    if constexpr (GX) gx_store8(reinterpret_cast<unsigned char*>(y), e0, v, 1.0f, (float)(1 << GLC_GX_SHIFT), sat);      // (sat: fp8 range guard, glc_common.h)
+template <bool GX> __device__ __forceinline__ void row_store8(f16_t* y, int e0, const float (&v)[8], unsigned* sat = nullptr, int act_sc = 0) {
+    if constexpr (GX) gx_store8(reinterpret_cast<unsigned char*>(y), e0, v, gx_act_khi(act_sc), gx_act_klo(act_sc), sat);      // (sat: fp8 range guard; act_sc: activation exponent, glc_common.h)
     else gs_store8(y, e0, v);
 }
-template <bool GX> __device__ __forceinline__ void row_load8(const f16_t* y, int e0, float (&v)[8]) {
-    if constexpr (GX) gx_load8(reinterpret_cast<const unsigned char*>(y), e0, v, 1.0f / (float)(1 << GLC_GX_SHIFT));
+template <bool GX> __device__ __forceinline__ void row_load8(const f16_t* y, int e0, float (&v)[8], int act_sc = 0) {
+    if constexpr (GX) gx_load8(reinterpret_cast<const unsigned char*>(y), e0, v, gx_pow2_inv(gx_act_klo(act_sc)));
     else gs_load8(y, e0, v);
 }
 template <bool MASKED, bool GX = false>
 __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_t* __restrict__ y, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float eps, int H, float mk, int lane, unsigned* sat = nullptr) {
+                                               const float* __restrict__ beta, float eps, int H, float mk, int lane, unsigned* sat = nullptr, int act_sc = 0) {
     const int nch = H / 8;
     float v[MAXC][8];
     float s = 0.f;
@@ -105,20 +105,20 @@ __device__ __forceinline__ void ln_row_wave_gs(const float* __restrict__ x, f16_
                 if (MASKED) r *= mk;
                 o[e] = r;
             }
-            row_store8<GX>(y, ch * 8, o, sat);
+            row_store8<GX>(y, ch * 8, o, sat, act_sc);
         }
     }
 }
 template <bool GX>
 __global__ __launch_bounds__(256) void layernorm_gs_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, int M, int H, unsigned* sat) {
+                                                           const float* __restrict__ beta, float eps, int M, int H, unsigned* sat, int act_sc) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    ln_row_wave_gs<false, GX>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63, sat);
+    ln_row_wave_gs<false, GX>(X + (size_t)row * H, Y + (size_t)row * 2 * H, gamma, beta, eps, H, 1.f, threadIdx.x & 63, sat, act_sc);
 }
 // decoder backbone, RMSNorm folded into the GEMMs: the embedding rows (plain fp32) enter the pipeline as raw group-split rows + (0, rstd)
 template <bool GX>
-__global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H, unsigned* sat) {
+__global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __restrict__ X, f16_t* __restrict__ Y, float2* __restrict__ stats, float eps, int M, int H, unsigned* sat, int act_sc) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int lane = threadIdx.x & 63, nch = H / 8;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void rows_to_gs_rms_kernel(const float* __rest
         const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-        row_store8<GX>(y, ch * 8, v, sat);
+        row_store8<GX>(y, ch * 8, v, sat, act_sc);
     }
     ss = wave_sum(ss);
     if (lane == 0) stats[row] = make_float2(0.f, rsqrtf(ss / (float)H + eps));
@@ -157,7 +157,7 @@ template <bool GX>
 __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
                                                        const float* __restrict__ table, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, f16_t* __restrict__ X,
-                                                       float* __restrict__ kbias, int B, int S, int Sp, int H, int vocab, int pad_id, unsigned* sat) {
+                                                       float* __restrict__ kbias, int B, int S, int Sp, int H, int vocab, int pad_id, unsigned* sat, int act_sc) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row in the padded [B, Sp] grid
     if (row >= B * Sp) return;
     const int lane = threadIdx.x & 63;
@@ -170,13 +170,13 @@ __global__ __launch_bounds__(256) void embed_gs_kernel(const int64_t* __restrict
         if (id < 0 || id >= vocab) id = pad_id;
     }
     if (lane == 0) kbias[row] = mk != 0.f ? 0.f : GLC_NEG_BIG;
-    ln_row_wave_gs<true, GX>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane, sat);
+    ln_row_wave_gs<true, GX>(table + (size_t)id * H, X + (size_t)row * 2 * H, gamma, beta, eps, H, mk, lane, sat, act_sc);
 }
 // pruned last layer: rows the head reads, GS hidden states -> plain fp32 compact rows (that layer runs on the fp32-format kernels)
 template <bool GX>
 __global__ __launch_bounds__(256) void gather_rows_gs_kernel(const f16_t* __restrict__ X, const int* __restrict__ cls_pos, int c_cap,
                                                              float* __restrict__ Xs, int* __restrict__ sel_b, int* __restrict__ sel_q,
-                                                             unsigned char* __restrict__ tile_flag, int B, int Sp, int H, int C) {
+                                                             unsigned char* __restrict__ tile_flag, int B, int Sp, int H, int C, int act_sc) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= B * (1 + C)) return;
     const int lane = threadIdx.x & 63;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gather_rows_gs_kernel(const f16_t* __rest
     const f16_t* src = X + ((size_t)b * Sp + pos) * 2 * H;
     for (int i = lane; i < H / 8; i += 64) {
         float v[8];
-        row_load8<GX>(src, i * 8, v);
+        row_load8<GX>(src, i * 8, v, act_sc);
         *reinterpret_cast<f32x4*>(Xs + (size_t)r * H + i * 8) = (f32x4){v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(Xs + (size_t)r * H + i * 8 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     }
@@ -473,8 +473,8 @@ const char* glc_launch_embed(hipStream_t st, int dtype, const int64_t* ids, cons
 const char* glc_launch_layernorm_gs(hipStream_t st, const float* X, void* Y, const float* gamma, const float* beta, float eps, int M, int H, int gx) {
     if (M <= 0 || !X || !Y || !gamma || !beta) return "layernorm_gs: bad args";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "layernorm_gs: unsupported hidden size";
-    if (gx) hipLaunchKernelGGL(layernorm_gs_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, glc_gx_sat_ptr());
-    else hipLaunchKernelGGL(layernorm_gs_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, (unsigned*)nullptr);
+    if (gx) hipLaunchKernelGGL(layernorm_gs_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, glc_gx_sat_ptr(), glc_gx_act_sc());
+    else hipLaunchKernelGGL(layernorm_gs_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, gamma, beta, eps, M, H, (unsigned*)nullptr, 0);
     return nullptr;
 }
 
@@ -486,8 +486,8 @@ const char* glc_launch_ln_stats(hipStream_t st, const float2* part, int nparts, 
 
 const char* glc_launch_rows_to_gs_rms(hipStream_t st, const float* X, void* Y, float2* stats, float eps, int M, int H, int gx) {
     if (!X || !Y || !stats || M <= 0 || H <= 0 || H % 32) return "rows_to_gs_rms: bad args";
-    if (gx) hipLaunchKernelGGL(rows_to_gs_rms_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H, glc_gx_sat_ptr());
-    else hipLaunchKernelGGL(rows_to_gs_rms_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H, (unsigned*)nullptr);
+    if (gx) hipLaunchKernelGGL(rows_to_gs_rms_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H, glc_gx_sat_ptr(), glc_gx_act_sc());
+    else hipLaunchKernelGGL(rows_to_gs_rms_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, X, (f16_t*)Y, stats, eps, M, H, (unsigned*)nullptr, 0);
     return nullptr;
 }
 
@@ -496,8 +496,8 @@ const char* glc_launch_embed_gs(hipStream_t st, const int64_t* ids, const int64_
     if (B <= 0 || S <= 0 || Sp < S || !ids || !mask || !table || !X || !kbias) return "embed_gs: bad args";
     if (pad_id < 0 || pad_id >= vocab) return "embed_gs: pad id outside vocab";
     if (H <= 0 || H % 32 || H / 8 > 64 * MAXC) return "embed_gs: unsupported hidden size";
-    if (gx) hipLaunchKernelGGL(embed_gs_kernel<true>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id, glc_gx_sat_ptr());
-    else hipLaunchKernelGGL(embed_gs_kernel<false>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id, (unsigned*)nullptr);
+    if (gx) hipLaunchKernelGGL(embed_gs_kernel<true>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id, glc_gx_sat_ptr(), glc_gx_act_sc());
+    else hipLaunchKernelGGL(embed_gs_kernel<false>, dim3((B * Sp + 3) / 4), dim3(256), 0, st, ids, mask, table, gamma, beta, eps, (f16_t*)X, kbias, B, S, Sp, H, vocab, pad_id, (unsigned*)nullptr, 0);
     return nullptr;
 }
 
@@ -505,8 +505,8 @@ const char* glc_launch_gather_rows_gs(hipStream_t st, const void* X, const int* 
                                       unsigned char* tile_flag, int B, int Sp, int H, int C, int gx) {
     if (B <= 0 || C < 0 || !X || !cls_pos || !Xs || !sel_b || !sel_q || H % 32) return "gather_rows_gs: bad args";
     const int rows = B * (1 + C);
-    if (gx) hipLaunchKernelGGL(gather_rows_gs_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
-    else hipLaunchKernelGGL(gather_rows_gs_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C);
+    if (gx) hipLaunchKernelGGL(gather_rows_gs_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C, glc_gx_act_sc());
+    else hipLaunchKernelGGL(gather_rows_gs_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, (const f16_t*)X, cls_pos, c_cap, Xs, sel_b, sel_q, tile_flag, B, Sp, H, C, 0);
     return nullptr;
 }
 

@@ -140,6 +140,10 @@ class Engine:
         """the engine has left the MX pipeline for good (outlier channels in consecutive forwards)"""
         return bool(self.L.glc_debug_fp8_range_sticky(self.h))
 
+    def activation_exponent(self):
+        """exponent of the MX pipeline's activation rows: 0, or -5 once a forward left the fp8 range (the guard's first answer)"""
+        return int(self.L.glc_debug_activation_exponent(self.h))
+
     def set_mx2(self, on):
         """MX attention on the bucket-space kernel (attention_mx2.hip) or on the band kernel (attention_mx.hip)"""
         self.L.glc_debug_set_mx2(self.h, int(bool(on)))

@@ -170,6 +170,9 @@ int glc_debug_range_retries(const glc_engine* e);
  * operand images (|x| > 448); 1 once the engine has left the MX pipeline for good (two such forwards in a row, or one seen by glc_engine_sync) */
 int glc_debug_fp8_range_retries(const glc_engine* e);
 int glc_debug_fp8_range_sticky(const glc_engine* e);
+/* ... and the exponent the engine's activation rows carry: 0, or -5 once a forward left the range (the guard's first answer: rows that hold
+ * |x| up to 14336, the forward repeated on the MX pipeline; only what still leaves the range goes to the split-f16 kernels) */
+int glc_debug_activation_exponent(const glc_engine* e);
 /* 256-tile GEMM ring: full-line (operand-major) stages on / off, process-wide developer A/B switch; bit-identical results. */
 int glc_debug_set_gemm_full_lines(int on);
 

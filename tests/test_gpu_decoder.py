@@ -68,6 +68,12 @@ def test_decoder_head_dim_64_and_long_sequence(dtype, weights_for):
             ref = oracle_c.forward(cfg, w, ids, mask)
             got = eng.forward(ids, mask)
             assert np.abs(sig(got) - sig(ref)).max() <= TOL_PROB[dtype], (B, S)
+            if dtype == "f32":      # the D = 64 instantiations of the MX pipeline's layout pass and LDS-ring attention (decoder_mx.hip; no RoPE epilogue at head_dim 64)
+                eng.set_group_split(2)
+                mx = eng.forward(ids, mask)
+                eng.set_group_split(1)
+                assert eng.last_mx() and eng.last_mx_attention(), "the MX pipeline did not run"
+                assert np.abs(sig(mx) - sig(ref)).max() <= 3e-4, (B, S)
     finally:
         eng.close()
 
@@ -97,6 +103,13 @@ def test_decoder_config_switches(variant, weights_for):
             m = mask.astype(bool)
             for which in range(cfg.layers + 1):
                 assert np.abs(eng.hidden(which, B, S)[m] - hid[which][m]).max() <= 3e-4, which
+            # the same switches on the forced MX pipeline: non-causal walks of the LDS-ring attention, one query head per kv head ("mha":
+            # two kv heads, so the QKV projection also takes the RoPE epilogue), first-token pooling
+            eng.set_group_split(2)
+            mx = eng.forward(ids, mask)
+            eng.set_group_split(1)
+            assert eng.last_mx() and eng.last_mx_attention(), "the MX pipeline did not run"
+            assert np.abs(sig(mx) - sig(ref)).max() <= 3e-4, (variant, B, S)
     finally:
         eng.close()
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(fa[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sa + i * 8 * LINE);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(fw[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sw + i * 8 * LINE);
+        for (int i = 0; i < (ABL == 7 ? 3 : 4); ++i) glds16(fw[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sw + i * 8 * LINE);      // (ABL 7: 7 of 8 KiB per wave and group, as 112-byte row groups would move)
     };
 
     f32x16 acc[4][2];
@@ -137,7 +137,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 #pragma unroll
         for (int j = 0; j < 2; ++j) { w16[j][0] = w16[j][1] = (f16x8)(f16_t)(0.002f * lane); xw[j] = (i32x8)(0x38383838 - lane); }
     }
-    const int pm = p.prio_mode;               // 0: no priorities; 1: MFMA phase at priority 1; 2: load phase at priority 2; 3: the late wave group at priority 1 throughout
+    const int pm = ABL ? 1 : p.prio_mode;     // (timing-only builds: the default policy)  0: no priorities; 1: MFMA phase at priority 1; 2: load phase at priority 2; 3: the late wave group at priority 1 throughout
     if (pm == 3 && wm == 1) __builtin_amdgcn_s_setprio(1);
     stage_fl(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -148,6 +148,14 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         const i32x4 t1 = *reinterpret_cast<const i32x4*>(q0 + o1);
         i32x8 r;
         r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+        return r;
+    };
+    auto ld24 = [&](const unsigned char* q0, int o0, int o1) __attribute__((always_inline)) {      // (ABL 7) one 16-byte and one 8-byte chunk
+        typedef __attribute__((ext_vector_type(2))) int i32x2;
+        const i32x4 t0 = *reinterpret_cast<const i32x4*>(q0 + o0);
+        const i32x2 t1 = *reinterpret_cast<const i32x2*>(q0 + o1);
+        i32x8 r;
+        r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = 0; r[7] = 0;
         return r;
     };
     auto sub = [&](const int s, const int odd) __attribute__((always_inline)) {
@@ -171,6 +179,11 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                     a16[i][0] = *reinterpret_cast<const f16x8*>(sa + i * 32 * LINE + ck0);
                     a16[i][1] = *reinterpret_cast<const f16x8*>(sa + i * 32 * LINE + ck1);
                 }
+            } else if constexpr (ABL == 7) {      // (timing only: 24 instead of 32 bytes per lane and block, as fp6 parts would be read)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xw[j] = ld24(sw + j * 32 * LINE, cx0, cx1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[i] = ld24(sa + i * 32 * LINE, cx0, cx1);
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) xw[j] = ld32(sw + j * 32 * LINE, cx0, cx1);      // [w_hi8 w_lo8 | w_hi8 w_lo8] of 2 x 8 elements
@@ -203,6 +216,8 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if constexpr (ABL == 7) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xw[j], xa[i], acc[i][j], 2, 2, 0, sc_w, 0, sc_a);      // (timing only: both operands read as e2m3)
+                    else
                     if (!VMODE) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xw[j], xa[i], acc[i][j], 0, 0, 0, sc_w, 0, sc_a);
                     else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[i], xw[j], acc[i][j], 0, 0, 0, sc_a, 0, sc_w);
                 }
@@ -553,9 +568,12 @@ __global__ __launch_bounds__(512, 2) void gemm256x_qkvr_kernel(GemmArgs p, int n
 
 template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
     if constexpr (!DIAG && ABL == 0 && EPI == EPI_BIAS && !VMODE) {
+#ifdef GLC_DEVELOPER      // timing-only builds of the main loop (scripts/gemm_mx_ablate.py): 4 no fragment reads, 5 no DMA, 6 no MFMAs, 7 the traffic and MFMA format of fp6 cross terms
         if (a.prio_mode == 4) return a.stamps ? launch_x<EPI, VMODE, true, 4>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 4>(st, a, n_tile0, ntn);
         if (a.prio_mode == 5) return a.stamps ? launch_x<EPI, VMODE, true, 5>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 5>(st, a, n_tile0, ntn);
         if (a.prio_mode == 6) return a.stamps ? launch_x<EPI, VMODE, true, 6>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 6>(st, a, n_tile0, ntn);
+        if (a.prio_mode == 7) return a.stamps ? launch_x<EPI, VMODE, true, 7>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 7>(st, a, n_tile0, ntn);
+#endif
         if (a.stamps) return launch_x<EPI, VMODE, true>(st, a, n_tile0, ntn);
     }
     static std::atomic<unsigned> lds_ok{0};

@@ -1623,7 +1623,8 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
     which %= 1000;
     const int which_in = which;
     if (which >= 100) which %= 100;
-    const bool mxb = which == 9 || which == 10;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
+    const bool gyb = which == 11 || which == 12;      // the same kernel on GY rows (e2m3 parts with block scales); 12: plus one stamped launch
+    const bool mxb = which == 9 || which == 10 || gyb;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
     const bool gsb = which == 6 || which == 8 || mxb;
     const int mx_ws = glc_gx_weight_exponent(0.5f);
     if (!e || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (e->dtype == GLC_F32 && !gsb) || epi < EPI_BIAS || epi > EPI_RESID) { set_err("gemm_bench: bad args"); return -1.f; }
@@ -1640,12 +1641,14 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
             hipMalloc((void**)&bias, N * sizeof(float)) || hipMalloc((void**)&tmp, nmax * sizeof(float))) { set_err("gemm_bench: alloc failed"); break; }
         std::vector<float> h(nmax);
         unsigned s = 12345u;
-        for (size_t i = 0; i < nmax; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((float)(s >> 8) / 8388608.f - 1.f) * 0.5f; }
+        const char* zenv = getenv("GLC_BENCH_DATA");       // developer: "zero" = all-zero operands, "const" = one value everywhere (how much of the time is the power envelope?)
+        for (size_t i = 0; i < nmax; ++i) { s = s * 1664525u + 1013904223u; h[i] = zenv && zenv[0] == 'z' ? 0.f : zenv && zenv[0] == 'c' ? 0.37f : ((float)(s >> 8) / 8388608.f - 1.f) * 0.5f; }
         if (hipMemcpy(tmp, h.data(), nmax * sizeof(float), hipMemcpyHostToDevice)) { set_err("gemm_bench: copy failed"); break; }
         if (gsb) {      // fp32 values, split in place into the group-split image (or the GX image)
             if (hipMemcpyAsync(A, tmp, nA * 4, hipMemcpyDeviceToDevice, e->stream) || hipMemcpyAsync(W, tmp, nW * 4, hipMemcpyDeviceToDevice, e->stream) ||
                 hipMemcpyAsync(R, tmp, nC * 4, hipMemcpyDeviceToDevice, e->stream)) { set_err("gemm_bench: copy failed"); break; }
-            if (mxb ? (glc_launch_to_gx(e->stream, A, nA, 0, 0) || glc_launch_to_gx(e->stream, W, nW, mx_ws, 1) || glc_launch_to_gx(e->stream, R, nC, 0, 0))
+            if (gyb ? (glc_launch_to_gy(e->stream, tmp, A, M, K, 0) || glc_launch_to_gy(e->stream, tmp, W, N, K, 1) || glc_launch_to_gy(e->stream, tmp, R, M, N, 0)) :
+                mxb ? (glc_launch_to_gx(e->stream, A, nA, 0, 0) || glc_launch_to_gx(e->stream, W, nW, mx_ws, 1) || glc_launch_to_gx(e->stream, R, nC, 0, 0))
                     : (glc_launch_presplit(e->stream, A, nA) || glc_launch_presplit(e->stream, W, nW) || glc_launch_presplit(e->stream, R, nC))) { set_err("gemm_bench: split failed"); break; }
         } else
         if (glc_launch_convert(e->stream, e->dtype, tmp, A, nA) || glc_launch_convert(e->stream, e->dtype, tmp, W, nW) ||
@@ -1654,6 +1657,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         GemmArgs g; g.A = A; g.W = W; g.bias = bias; g.C = C; g.resid = R; g.Mpad = M; g.N = N; g.K = K; g.mx_ws = mx_ws;
         if (mxb && which_in >= 100) g.prio_mode = which_in / 100 - 1;      // which = 100 (1 + prio) + 9 | 10
         g.epi_abl = mxb ? epi_abl : 0;
+        g.gy = gyb ? 1 : 0;
         const char* m = nullptr;
         auto launch = [&]() -> const char* { return mxb ? glc_launch_gemm256x(e->stream, epi, g) : gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 5 || which == 7) ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
@@ -1664,13 +1668,13 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         float t = 0.f;
         if (hipEventElapsedTime(&t, e->t0, e->t1)) break;
         ms = t / iters;
-        if (which == 7 || which == 8 || which == 10) {     // diagnostic: one stamped launch of the full-line 256-tile kernel (7: 16-bit operands, 8: group-split), EPI_BIAS
+        if (which == 7 || which == 8 || which == 10 || which == 12) {     // diagnostic: one stamped launch of the full-line 256-tile kernel (7: 16-bit operands, 8: group-split), EPI_BIAS
             unsigned long long* dbuf = nullptr;
             const size_t ns = 64 * 8 * 14;
             if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
                 (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), e->stream);
                 GemmArgs gd = g; gd.stamps = dbuf;
-                const char* dm = which == 10 ? glc_launch_gemm256x(e->stream, EPI_BIAS, gd) : which == 8 ? glc_launch_gemm256s_gs(e->stream, EPI_BIAS, gd) : glc_launch_gemm256s(e->stream, e->dtype, EPI_BIAS, gd);
+                const char* dm = (which == 10 || which == 12) ? glc_launch_gemm256x(e->stream, EPI_BIAS, gd) : which == 8 ? glc_launch_gemm256s_gs(e->stream, EPI_BIAS, gd) : glc_launch_gemm256s(e->stream, e->dtype, EPI_BIAS, gd);
                 (void)hipStreamSynchronize(e->stream);
                 std::vector<unsigned long long> hs(ns);
                 if (!dm && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1679,7 +1683,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
                         for (int b = 0; b < 64; ++b) for (int w = 4 * grp; w < 4 * grp + 4; ++w) for (int k = 0; k < 12; ++k) sg[k] += (double)hs[((size_t)b * 8 + w) * 12 + k];
                         const double n = 64 * 4, ng = sg[11] / n > 0 ? sg[11] / n : 1;
                         fprintf(stderr, "[gemm256s stamps M=%d N=%d K=%d %s, waves %d-%d] cycles per group and wave: E: dma %.0f reads+wait %.0f barrier %.0f mfma %.0f barrier %.0f | "
-                                        "O: (dma %.0f) reads+wait %.0f barrier %.0f mfma %.0f barrier %.0f | total %.0f | clock %.0f MHz\n", M, N, K, which == 10 ? "MX" : which == 8 ? "group-split" : "16-bit", 4 * grp, 4 * grp + 3,
+                                        "O: (dma %.0f) reads+wait %.0f barrier %.0f mfma %.0f barrier %.0f | total %.0f | clock %.0f MHz\n", M, N, K, which == 12 ? "MX on GY rows" : which == 10 ? "MX" : which == 8 ? "group-split" : "16-bit", 4 * grp, 4 * grp + 3,
                                 sg[0] / n / ng, sg[1] / n / ng, sg[2] / n / ng, sg[3] / n / ng, sg[4] / n / ng, sg[5] / n / ng, sg[6] / n / ng, sg[7] / n / ng, sg[8] / n / ng, sg[9] / n / ng,
                                 (sg[0] + sg[1] + sg[2] + sg[3] + sg[4] + sg[5] + sg[6] + sg[7] + sg[8] + sg[9]) / n / ng, sg[10] / n / 10.0);
                     }
@@ -1703,6 +1707,9 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
  * out[0] = max |mx - gs|, out[1] = max |gs|, out[2] = rms(mx - gs), out[3] = rms(gs) over the decoded outputs (mode 2: + the ln_part
  * sums in out[4] = max |diff|).  Returns 0 or < 0. */
 int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, int mode, double* out) {
+    const bool gy = mode >= 10;          // mode + 10: the MX leg on GY rows (e2m3 parts with block scales) instead of GX rows
+    if (gy) mode -= 10;
+    if (gy && (K % 64 || N % 64)) { set_err("gemm_mx_check: GY rows need K, N % 64 == 0"); return -1; }
     if (!e || !out || M <= 0 || N <= 0 || K <= 0 || M % 256 || N % 256 || K % 32 || mode < 0 || mode > 4) { set_err("gemm_mx_check: bad args"); return -1; }
     if (mode == 4 && (N % 768 || M % 256)) { set_err("gemm_mx_check: the QKV mode needs N = 3 H, H % 256 == 0"); return -1; }
     std::lock_guard<std::mutex> lk(e->mu);
@@ -1710,8 +1717,10 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
     const size_t nA = (size_t)M * K, nW = (size_t)N * K, nC = (size_t)M * N;
     float *A = nullptr, *W = nullptr, *A2 = nullptr, *W2 = nullptr, *C0 = nullptr, *C1 = nullptr, *R0 = nullptr, *R1 = nullptr, *bias = nullptr, *lnc = nullptr, *gam = nullptr, *bet = nullptr;
     float2 *st = nullptr, *lp0 = nullptr, *lp1 = nullptr;
+    void *Ay = nullptr, *Wy = nullptr, *Ry = nullptr, *Cy = nullptr;
     int rc = -1;
     do {
+        if (gy && (hipMalloc(&Ay, nA * 4) || hipMalloc(&Wy, nW * 4) || hipMalloc(&Ry, nC * 4) || hipMalloc(&Cy, nC * 4))) { set_err("gemm_mx_check: alloc failed"); break; }
         if (hipMalloc((void**)&A, nA * 4) || hipMalloc((void**)&W, nW * 4) || hipMalloc((void**)&A2, nA * 4) || hipMalloc((void**)&W2, nW * 4) ||
             hipMalloc((void**)&C0, nC * 4) || hipMalloc((void**)&C1, nC * 4) || hipMalloc((void**)&R0, nC * 4) || hipMalloc((void**)&R1, nC * 4) ||
             hipMalloc((void**)&bias, (size_t)N * 4) || hipMalloc((void**)&lnc, (size_t)N * 4) || hipMalloc((void**)&gam, (size_t)N * 4) || hipMalloc((void**)&bet, (size_t)N * 4) ||
@@ -1720,11 +1729,15 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
         std::vector<float2> hst(M);
         unsigned s = 777u + 13u * mode;
         auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 8388608.f - 1.f; };
+        const bool special = a_amp < 0.f;      // developer: a = 1 + 2^-12 (hi 1, lo 2^-12), w = 1, no bias: every output = K (1 + 2^-12) iff the a_lo w_hi terms arrive
+        const int spec = special ? (int)(-a_amp + 0.5f) : 0;      // 1: a = 1 + 2^-12, w = 1; 2: a = 1, w = 1 + 2^-12; 3: both; 4: a = 3 + 3 2^-12 (hi 3, lo), w = 1
+        if (special) a_amp = 1.f;
         for (auto& v : ha) v = rnd() * a_amp;
         for (auto& v : hw) v = rnd() * w_amp;
         for (auto& v : hr) v = rnd() * a_amp;
         for (int n = 0; n < N; ++n) { hb[n] = rnd() * 0.1f; hc[n] = rnd() * 0.05f; hg[n] = 1.f + 0.3f * rnd(); hbe[n] = 0.2f * rnd(); }
         for (int m = 0; m < M; ++m) hst[m] = make_float2(0.1f * rnd() * a_amp, (0.5f + 0.4f * rnd()) / a_amp);
+        if (special) { const float d = ldexpf(1.f, -12); for (auto& v : ha) v = spec == 2 ? 1.0f : spec == 4 ? 3.0f + 3.0f * d : 1.0f + d; for (auto& v : hw) v = spec >= 2 && spec <= 3 ? 1.0f + d : 1.0f; for (auto& v : hb) v = 0.f; }
         if (hipMemcpy(A, ha.data(), nA * 4, hipMemcpyHostToDevice) || hipMemcpy(W, hw.data(), nW * 4, hipMemcpyHostToDevice) ||
             hipMemcpy(A2, ha.data(), nA * 4, hipMemcpyHostToDevice) || hipMemcpy(W2, hw.data(), nW * 4, hipMemcpyHostToDevice) ||
             hipMemcpy(R0, hr.data(), nC * 4, hipMemcpyHostToDevice) || hipMemcpy(R1, hr.data(), nC * 4, hipMemcpyHostToDevice) ||
@@ -1735,9 +1748,15 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
         const char* m = glc_launch_presplit(e->stream, A, nA);
         if (!m) m = glc_launch_presplit(e->stream, W, nW);
         if (!m) m = glc_launch_presplit(e->stream, R0, nC);
+        if (gy) {
+            if (!m) m = glc_launch_to_gy(e->stream, A2, Ay, M, K, 0);
+            if (!m) m = glc_launch_to_gy(e->stream, W2, Wy, N, K, 1);
+            if (!m) m = glc_launch_to_gy(e->stream, R1, Ry, M, N, 0);
+        } else {
         if (!m) m = glc_launch_to_gx(e->stream, A2, nA, 0, 0);
         if (!m) m = glc_launch_to_gx(e->stream, W2, nW, ws, 1);
         if (!m) m = glc_launch_to_gx(e->stream, R1, nC, 0, 0);
+        }
         GemmArgs g; g.bias = bias; g.Mpad = M; g.N = N; g.K = K;
         int epi = EPI_BIAS;
         if (mode == 0) g.gs_c_plain = 1;
@@ -1750,7 +1769,10 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
         if (!m) m = glc_launch_gemm256s_gs(e->stream, epi, g);
         g.A = A2; g.W = W2; g.C = C1; g.resid = R1; g.mx_ws = ws; if (mode == 2) g.ln_part = lp1;
         if (mode == 4) { g.Qh = C1; g.Kh = C1 + third; g.Vt = C1 + 2 * third; }
+        const bool rows_out = mode == 1 || mode == 2;
+        if (gy) { g.gy = 1; g.A = Ay; g.W = Wy; g.resid = Ry; if (rows_out) g.C = Cy; if (getenv("GLC_GY_DIRECT_SCALES")) g.epi_abl = 9; }
         if (!m) m = glc_launch_gemm256x(e->stream, epi, g);
+        if (gy && rows_out && !m) m = glc_launch_gy_to_f32(e->stream, Cy, C1, M, N);        // (the GY output rows decoded on the device)
         if (m) { set_err(m); break; }
         std::vector<float> c0(nC), c1(nC);
         if (hipStreamSynchronize(e->stream) || hipMemcpy(c0.data(), C0, nC * 4, hipMemcpyDeviceToHost) || hipMemcpy(c1.data(), C1, nC * 4, hipMemcpyDeviceToHost)) { set_err("gemm_mx_check: readback failed"); break; }
@@ -1769,6 +1791,8 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
             if (rows_gs) {
                 const size_t row = i / N, col = i % N, grp = col >> 5, e5 = col & 31;
                 v0 = half_at(c0.data(), (row * N + grp * 32) * 2 + e5) + half_at(c0.data(), (row * N + grp * 32) * 2 + 32 + e5);
+                if (gy) v1 = c1[i];
+                else
                 v1 = half_at(c1.data(), (row * N + grp * 32) * 2 + e5) + fp8_at(c1.data(), (row * N + grp * 32) * 4 + 64 + 16 * (e5 >> 3) + (e5 & 7)) * ldexp(1.0, -GLC_GX_SHIFT);
             } else if (units) {
                 const size_t u = i >> 3, j = i & 7;
@@ -1781,6 +1805,15 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
             sd += d * d; sr += v0 * v0;
         }
         out[0] = md; out[1] = mr; out[2] = sqrt(sd / nC); out[3] = sqrt(sr / nC); out[4] = 0;
+        if (special && gy) {
+            unsigned char ra[128], rw[128];
+            (void)hipMemcpy(ra, (const unsigned char*)Ay + 64, 48, hipMemcpyDeviceToHost); (void)hipMemcpy(rw, (const unsigned char*)Wy + 64, 48, hipMemcpyDeviceToHost);
+            fprintf(stderr, "  Ay row 0 fp6 area:"); for (int i = 0; i < 48; ++i) fprintf(stderr, " %02x", ra[i]);
+            fprintf(stderr, "\n  Wy row 0 fp6 area:"); for (int i = 0; i < 48; ++i) fprintf(stderr, " %02x", rw[i]);
+            (void)hipMemcpy(ra, (const unsigned char*)Ay + (size_t)(K / 32) * 112, 4, hipMemcpyDeviceToHost); (void)hipMemcpy(rw, (const unsigned char*)Wy + (size_t)(K / 32) * 112, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "\n  scale bytes A %d %d %d %d  W %d %d %d %d\n", ra[0], ra[1], ra[2], ra[3], rw[0], rw[1], rw[2], rw[3]);
+        }
+        if (special) fprintf(stderr, "[gemm_mx_check special] K = %d: split-f16 C[0] = %.6f, MX leg C[0] = %.6f C[1] = %.6f C[N+5] = %.6f; (case %d)\n", K, c0[0], c1[0], c1[1], c1[N + 5], spec);
         if (mode == 2) {
             std::vector<float2> p0((size_t)M * (N / 64)), p1(p0.size());
             if (hipMemcpy(p0.data(), lp0, p0.size() * 8, hipMemcpyDeviceToHost) || hipMemcpy(p1.data(), lp1, p1.size() * 8, hipMemcpyDeviceToHost)) { set_err("gemm_mx_check: readback failed"); break; }
@@ -1792,6 +1825,7 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
     } while (0);
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(A2); (void)hipFree(W2); (void)hipFree(C0); (void)hipFree(C1); (void)hipFree(R0); (void)hipFree(R1);
     (void)hipFree(bias); (void)hipFree(lnc); (void)hipFree(gam); (void)hipFree(bet); (void)hipFree(st); (void)hipFree(lp0); (void)hipFree(lp1);
+    (void)hipFree(Ay); (void)hipFree(Wy); (void)hipFree(Ry); (void)hipFree(Cy);
     return rc;
 }
 

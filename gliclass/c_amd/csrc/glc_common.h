@@ -289,6 +289,125 @@ __device__ __forceinline__ void gx_load8(const unsigned char* row, int e0, float
     gx_decode8(*reinterpret_cast<const gs_h8*>(p + (e0 & 31) * 2), *reinterpret_cast<const u32x2*>(p + 64 + (e0 & 31) * 2), inv_lo, v);
 }
 
+// ---- "GY" operand images (round 4; the MX cross-term GEMM with e2m3 parts and per-block scales — "MX proper") ----
+// Same split product as GX rows (a w = a_hi w_hi in f16 + both cross terms in ONE block-scaled MFMA), but the 8-bit e4m3 parts with a fixed
+// exponent become 6-bit e2m3 parts (the same 4 significant bits) with an e8m0 scale per block of 16 elements: the scaled MFMA runs at
+// twice the fp8 rate (32 instead of 64 cycles per 32x32x64), a row group shrinks from 128 to 112 bytes on both data paths of the GEMM loop, the
+// conversion is ONE v_cvt_scalef32_2xpk16_fp6_f32 per 16 elements (16 v_cvt_scalef32_pk_fp8_f32 before), and activations need no range
+// guard.  Semantics pinned by scripts/probes/mx6_probe.hip (profiles/r04/mx6_probe.txt); timing-only case profiles/r04/gemm_fp6_shaped.txt.
+// A matrix of `rows` rows x K elements (K % 64 == 0) is stored GROUP-MAJOR — [K / 32 groups][rows][112 bytes], then the scales
+// [K / 64 group pairs][rows][4 bytes] — so that what the GEMM stages per K step (one group of 256 consecutive rows) is 28 KiB of consecutive
+// whole cache lines (a 112-byte group inside a row-major row would straddle two lines, and every line would be fetched twice).
+// gy_bytes(rows, K) = rows (3.5 K + K / 16): inside the 4 K bytes per row the GX / GS images take.  Group (g, row):
+//   [ 64 B: 32 x f16 hi | 16 B: block 0 bytes 0..15 | 16 B: block 1 bytes 0..15 | 8 B: block 0 bytes 16..23 | 8 B: block 1 bytes 16..23 ]
+// block h = elements 16 h .. 16 h + 15 of the group as 32 packed e2m3 values, value 2 i = P0(element i), value 2 i + 1 = P1(element i) — the
+// order the conversion instruction interleaves its two sources in — with (P0, P1) = (lo 2^11, hi) for activations ("A order") and
+// (hi, lo 2^11) for weights ("W order"), lo = x - f16(x): an MFMA lane (row, h) reads its block as one 16-byte and one 8-byte piece at the
+// same offsets for both h, and the 64 k-slots pair a_lo with w_hi and a_hi with w_lo slot by slot.  Scale byte of (g, h, row): byte
+// 2 (g & 1) + h of the row's dword in pair g >> 1.  With E = the exponent of the block's largest |x| (largest part lands in [4, 8); e2m3
+// tops out at 7.5 and saturates), W order stores 127 + E - 2, A order 127 + E - 2 - 11 — the byte the MFMA takes as it is (the 2^-11 of
+// the cross terms rides on the A side), and the factor that turns an A image's lo parts back into lo (x = hi + e2m3 2^(b - 127)).
+__host__ __device__ inline size_t gy_bytes(size_t rows, int K) { return rows * ((size_t)(K >> 5) * 112 + (size_t)(K >> 4)); }
+__host__ __device__ inline size_t gy_group_off(size_t rows, size_t row, int g) { return ((size_t)g * rows + row) * 112; }
+__host__ __device__ inline size_t gy_scale_off(size_t rows, int K, size_t row, int g) { return (size_t)(K >> 5) * rows * 112 + ((size_t)(g >> 1) * rows + row) * 4 + 2 * (g & 1); }
+typedef __attribute__((ext_vector_type(16))) float gy_f16v;
+typedef __attribute__((ext_vector_type(32))) float gy_f32v;
+typedef __attribute__((ext_vector_type(6))) int gy_i6;
+// The two fp6 conversions through inline assembly with an EARLY-CLOBBER destination: left to the register allocator, the 6-register result of
+// v_cvt_scalef32_2xpk16_fp6_f32 lands on top of one of its 16-register sources (it did in every instance of this library), and the
+// instruction then converts values it has already overwritten — measured: W-order rows whose hi parts came out saturated.
+__device__ __forceinline__ gy_i6 gy_cvt_2x16(const gy_f16v& s0, const gy_f16v& s1, float scale) {
+    gy_i6 r;
+    asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(s0), "v"(s1), "v"(scale));
+    return r;
+}
+__device__ __forceinline__ gy_f32v gy_cvt_pk32_f32(const gy_i6& r, float scale) {
+    gy_f32v d;
+    asm("v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2" : "=&v"(d) : "v"(r), "v"(scale));
+    return d;
+}
+// 16 consecutive elements e0 .. e0 + 15 (e0 % 16 == 0) of row `row` = one block.  Returns the block's scale byte; SCALE = false leaves storing
+// it to the caller (the GEMM epilogues pack the four bytes of a row's 64 columns into one dword store).
+template <bool WORDER = false, bool NT = false, bool SCALE = true>
+__device__ __forceinline__ unsigned gy_store16(unsigned char* base, size_t rows, int K, size_t row, int e0, const float (&v)[16]) {
+    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+    for (int e = 2; e < 16; e += 2) m = fmaxf(fmaxf(m, fabsf(v[e])), fabsf(v[e + 1]));
+    uint32_t eb = __builtin_bit_cast(uint32_t, m) >> 23;          // biased exponent of the largest magnitude (m >= 0)
+    eb = eb < 16u ? 16u : (eb > 254u ? 254u : eb);                // (an all-zero / denormal block: any small scale does)
+    const float scale = __builtin_bit_cast(float, (eb - 2u) << 23);
+    gs_h8 h0, h1;
+    gy_f16v lo, hi;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const f16_t hv = (f16_t)v[e];
+        if (e < 8) h0[e] = hv; else h1[e - 8] = hv;
+        hi[e] = (float)hv;
+        lo[e] = (v[e] - (float)hv) * (float)(1 << GLC_GX_SHIFT);
+    }
+    const gy_i6 r = WORDER ? gy_cvt_2x16(hi, lo, scale) : gy_cvt_2x16(lo, hi, scale);
+    const int g = e0 >> 5, h = (e0 >> 4) & 1;
+    unsigned char* p = base + gy_group_off(rows, row, g);
+    const u32x4 r4 = {(uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]};
+    const u32x2 r2 = {(uint32_t)r[4], (uint32_t)r[5]};
+    if constexpr (NT) {
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, h0), reinterpret_cast<u32x4*>(p + 32 * h));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, h1), reinterpret_cast<u32x4*>(p + 32 * h + 16));
+        __builtin_nontemporal_store(r4, reinterpret_cast<u32x4*>(p + 64 + 16 * h));
+        __builtin_nontemporal_store(r2, reinterpret_cast<u32x2*>(p + 96 + 8 * h));
+    } else {
+        *reinterpret_cast<gs_h8*>(p + 32 * h) = h0;
+        *reinterpret_cast<gs_h8*>(p + 32 * h + 16) = h1;
+        *reinterpret_cast<u32x4*>(p + 64 + 16 * h) = r4;
+        *reinterpret_cast<u32x2*>(p + 96 + 8 * h) = r2;
+    }
+    const unsigned b = WORDER ? eb - 2u : eb - 2u - GLC_GX_SHIFT;
+    if constexpr (SCALE) base[gy_scale_off(rows, K, row, g) + h] = (unsigned char)b;
+    return b;
+}
+// 8 consecutive elements e0 .. e0 + 7 (e0 % 8 == 0) per lane, the lane `partner` (lane ^ partner_xor) holding the other half of the block
+// (both lanes must be active): the producers that have 8 values per lane (row kernels, attention context epilogues); A order
+__device__ __forceinline__ void gy_store8_pair(unsigned char* base, size_t rows, int K, size_t row, int e0, const float (&v)[8], int partner_xor) {
+    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+    for (int e = 2; e < 8; e += 2) m = fmaxf(fmaxf(m, fabsf(v[e])), fabsf(v[e + 1]));
+    m = fmaxf(m, __shfl_xor(m, partner_xor, 64));
+    uint32_t eb = __builtin_bit_cast(uint32_t, m) >> 23;
+    eb = eb < 16u ? 16u : (eb > 254u ? 254u : eb);
+    const float scale = __builtin_bit_cast(float, (eb - 2u) << 23);
+    gs_h8 hh;
+    gy_f16v s0, s1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const f16_t hv = (f16_t)v[e]; hh[e] = hv; s1[e] = (float)hv; s0[e] = (v[e] - (float)hv) * (float)(1 << GLC_GX_SHIFT); }
+#pragma unroll
+    for (int e = 8; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    const gy_i6 r = gy_cvt_2x16(s0, s1, scale);       // values 0 .. 15 (bytes 0 .. 11) are this lane's
+    const int g = e0 >> 5, h = (e0 >> 4) & 1, j = (e0 >> 3) & 1;
+    unsigned char* p = base + gy_group_off(rows, row, g);
+    *reinterpret_cast<gs_h8*>(p + (e0 & 31) * 2) = hh;
+    if (j == 0) {                                            // block bytes 0 .. 11
+        typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
+        *reinterpret_cast<u32x3*>(p + 64 + 16 * h) = (u32x3){(uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2]};
+        base[gy_scale_off(rows, K, row, g) + h] = (unsigned char)(eb - 2u - GLC_GX_SHIFT);
+    } else {                                                 // block bytes 12 .. 15 and 16 .. 23
+        *reinterpret_cast<uint32_t*>(p + 64 + 16 * h + 12) = (uint32_t)r[0];
+        *reinterpret_cast<u32x2*>(p + 96 + 8 * h) = (u32x2){(uint32_t)r[1], (uint32_t)r[2]};
+    }
+}
+// one block of an A-order image back to fp32: x = hi + lo, lo = e2m3 2^(b - 127)
+__device__ __forceinline__ void gy_decode16(const gs_h8& h0, const gs_h8& h1, const u32x4& r4, const u32x2& r2, unsigned b, float (&v)[16]) {
+    const gy_i6 r = {(int)r4[0], (int)r4[1], (int)r4[2], (int)r4[3], (int)r2[0], (int)r2[1]};
+    const gy_f32v d = gy_cvt_pk32_f32(r, __builtin_bit_cast(float, b << 23));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = (float)h0[e] + d[2 * e]; v[8 + e] = (float)h1[e] + d[16 + 2 * e]; }
+}
+__device__ __forceinline__ void gy_load16(const unsigned char* base, size_t rows, int K, size_t row, int e0, float (&v)[16]) {
+    const int g = e0 >> 5, h = (e0 >> 4) & 1;
+    const unsigned char* p = base + gy_group_off(rows, row, g);
+    gy_decode16(*reinterpret_cast<const gs_h8*>(p + 32 * h), *reinterpret_cast<const gs_h8*>(p + 32 * h + 16), *reinterpret_cast<const u32x4*>(p + 64 + 16 * h),
+                *reinterpret_cast<const u32x2*>(p + 96 + 8 * h), base[gy_scale_off(rows, K, row, g) + h], v);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

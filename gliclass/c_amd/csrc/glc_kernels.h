@@ -71,6 +71,7 @@ struct GemmArgs {
     int qkv_mxt = 0;                        // gemm256x, EPI_QKV: write Q / K / V^T as MX tiles (glc_layout.h) for attention_mx.hip instead of split-f16 units
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
     unsigned* gx_sat = nullptr;             // gemm256x: fp8 range guard counter (filled by the launcher from glc_gx_sat_ptr())
+    int gy = 0;                             // gemm256x: A, W, resid and C (where they are operand images) are GY rows — e2m3 parts with block scales (glc_common.h) — not GX rows
     int act_sc = 0;                         // gemm256x: exponent of the ACTIVATION GX rows it reads (A, resid) and writes (C); 0 unless the engine lowered it (engine.hip act_sc)
     int gx_rows = 0;                        // ... counted over rows [0, gx_rows) only: the slack rows up to Mpad hold leftovers of other forwards (0: Mvalid, else Mpad)
     // gemm256x, EPI_QKVR (decoder backbone, head_dim 128, nq and nkv even): N = (nq + 2 nkv) 128 fused projection columns; W rows (and bias)
@@ -132,6 +133,11 @@ const char* glc_launch_to_gx(hipStream_t st, void* w, size_t n, int sc, int word
 // the MX weight copies from the split-f16 (group-split) copies already on the device: largest magnitude (float bits, atomicMax into *d_bits), then the conversion
 const char* glc_launch_gs_absmax(hipStream_t st, const void* gs, size_t n, unsigned* d_bits);
 const char* glc_launch_gs_to_gx(hipStream_t st, const void* gs, void* gx, size_t n, int sc);
+// GY rows (glc_common.h: e2m3 parts with block scales, gy_row_bytes(K) per row): plain fp32 rows -> GY (A order / worder != 0: W order), the
+// projection weights from their split-f16 copies (W order), and back to fp32 (A order: x = hi + lo)
+const char* glc_launch_to_gy(hipStream_t st, const float* src, void* dst, size_t rows, int K, int worder);
+const char* glc_launch_gs_to_gy(hipStream_t st, const void* gs, void* dst, size_t rows, int K);
+const char* glc_launch_gy_to_f32(hipStream_t st, const void* src, float* dst, size_t rows, int K);
 #ifndef GLC_GX_SHIFT
 #define GLC_GX_SHIFT 11                     // GX rows: lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)) (glc_common.h)
 #endif

@@ -6,6 +6,9 @@
 //     scaled by the lane's own e8m0 byte (op_sel 0 = byte 0 of the scale register);
 //   * the accuracy of a_lo w_hi + a_hi w_lo from such parts (block = the 16 elements a lane holds, scale 2^(E - 2), E = exponent of the block's
 //     largest |x|) against the exact cross terms, for ordinary operands and for rows with an outlier of 3000.
+// NOTE: the conversion builtin lets the compiler place the 6-register result on top of a source tuple, and the instruction then reads values it has
+// already overwritten (found in gemm256x.hip's GY path; glc_common.h gy_cvt_2x16 uses inline assembly with an early-clobber result) — this probe's
+// allocation happened to be harmless.
 // One wave: A 32 rows x 32 elements, W 32 columns x 32 elements (one MFMA's worth).   hipcc --offload-arch=gfx950 -O2 mx6_probe.hip -o mx6_probe
 #include <hip/hip_runtime.h>
 #include <math.h>

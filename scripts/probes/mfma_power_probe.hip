@@ -1,0 +1,82 @@
+// Probe (developer, standalone; round 4): what the matrix pipe sustains under the chip's power envelope.  Every SIMD of the chip runs nothing
+// but v_mfma_f32_32x32x16_f16 (and, second case, v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3) on register operands — no memory, no LDS —
+// for a few milliseconds, with all-zero operands and with random ones.  The ratio is the envelope; the random-operand rate is the ceiling a
+// real GEMM's matrix pipe has on this part, whatever its schedule.   hipcc --offload-arch=gfx950 -O2 mfma_power_probe.hip -o mfma_power_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int KIND>
+__global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, float* __restrict__ out, int iters, unsigned long long* clk) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    unsigned s = seed[tid & 4095];
+    f16x8 a[4], b[4];
+    i32x8 xa[2], xb[2];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 8; ++e) {
+            s = s * 1664525u + 1013904223u; a[i][e] = (_Float16)(seed[4096] ? ((float)(s >> 8) / 8388608.f - 1.f) : 0.f);
+            s = s * 1664525u + 1013904223u; b[i][e] = (_Float16)(seed[4096] ? ((float)(s >> 8) / 8388608.f - 1.f) * 0.05f : 0.f);
+        }
+    for (int i = 0; i < 2; ++i)
+        for (int e = 0; e < 8; ++e) {
+            s = s * 1664525u + 1013904223u; xa[i][e] = seed[4096] ? (int)(s & 0x77777777u) : 0;      // (e4m3 bytes without the NaN pattern)
+            s = s * 1664525u + 1013904223u; xb[i][e] = seed[4096] ? (int)(s & 0x77777777u) : 0;
+        }
+    f32x16 c[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) c[i][e] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (KIND == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + u) & 3], b[i], c[i], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[(i + u) & 1], xb[i & 1], c[i], 0, 0, 0, 100, 0, 100);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float acc = 0.f;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc += c[i][e];
+    out[tid] = acc;
+    if (tid == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+int main() {
+    int ncu = 256;
+    hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess) ncu = prop.multiProcessorCount;
+    const int blocks = ncu * 2, threads = blocks * 256;             // 8 waves per CU = 2 per SIMD
+    unsigned* dseed; float* dout; unsigned long long* dclk;
+    hipMalloc(&dseed, 4097 * 4); hipMalloc(&dout, threads * 4); hipMalloc(&dclk, 16);
+    std::vector<unsigned> hs(4097);
+    for (int i = 0; i < 4096; ++i) hs[i] = 12345u + 7919u * i;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;
+    for (int kind = 0; kind < 2; ++kind)
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            hs[4096] = rnd;
+            hipMemcpy(dseed, hs.data(), 4097 * 4, hipMemcpyHostToDevice);
+            float best = 1e30f; unsigned long long hc[2] = {0, 0};
+            for (int rep = 0; rep < 6; ++rep) {                     // back to back: the later repetitions are the sustained figure
+                hipEventRecord(e0, 0);
+                if (kind == 0) hipLaunchKernelGGL(burn<0>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else hipLaunchKernelGGL(burn<1>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep >= 3 && ms < best) best = ms;
+                hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost);
+            }
+            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 64);
+            printf("%s, %s operands: %.3f ms for %d x 16 MFMAs per wave, 2 waves per SIMD on %d CUs: %.0f TFLOP/s; shader clock %.0f MHz\n",
+                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
+                   hc[1] ? (double)hc[0] * 100.0 / (double)hc[1] : 0.0);
+        }
+    return 0;
+}

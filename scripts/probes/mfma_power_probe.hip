@@ -10,6 +10,9 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 template <int KIND>
 __global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, float* __restrict__ out, int iters, unsigned long long* clk) {
@@ -36,6 +39,15 @@ __global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, f
             if constexpr (KIND == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + u) & 3], b[i], c[i], 0, 0, 0);
+            } else if constexpr (KIND == 2) {        // the same bits read as bf16
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(i + u) & 3]), __builtin_bit_cast(bf16x8, b[i]), c[i], 0, 0, 0);
+            } else if constexpr (KIND == 3) {        // int8 (32x32x32): the fp8 test's bytes
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const i32x4 ia = {xa[(i + u) & 1][0], xa[(i + u) & 1][1], xa[(i + u) & 1][2], xa[(i + u) & 1][3]}, ib = {xb[i & 1][0], xb[i & 1][1], xb[i & 1][2], xb[i & 1][3]};
+                    c[i] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(ia, ib, __builtin_bit_cast(i32x16, c[i]), 0, 0, 0));
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[(i + u) & 1], xb[i & 1], c[i], 0, 0, 0, 100, 0, 100);
@@ -59,7 +71,7 @@ int main() {
     for (int i = 0; i < 4096; ++i) hs[i] = 12345u + 7919u * i;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    for (int kind = 0; kind < 2; ++kind)
+    for (int kind = 0; kind < 4; ++kind)
         for (int rnd = 0; rnd < 2; ++rnd) {
             hs[4096] = rnd;
             hipMemcpy(dseed, hs.data(), 4097 * 4, hipMemcpyHostToDevice);
@@ -67,15 +79,17 @@ int main() {
             for (int rep = 0; rep < 6; ++rep) {                     // back to back: the later repetitions are the sustained figure
                 hipEventRecord(e0, 0);
                 if (kind == 0) hipLaunchKernelGGL(burn<0>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
-                else hipLaunchKernelGGL(burn<1>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 1) hipLaunchKernelGGL(burn<1>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 2) hipLaunchKernelGGL(burn<2>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else hipLaunchKernelGGL(burn<3>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep >= 3 && ms < best) best = ms;
                 hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost);
             }
-            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 ? 2.0 * 32 * 32 * 16 : 2.0 * 32 * 32 * 64);
+            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : 2.0 * 32 * 32 * 64);
             printf("%s, %s operands: %.3f ms for %d x 16 MFMAs per wave, 2 waves per SIMD on %d CUs: %.0f TFLOP/s; shader clock %.0f MHz\n",
-                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
+                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
                    hc[1] ? (double)hc[0] * 100.0 / (double)hc[1] : 0.0);
         }
     return 0;

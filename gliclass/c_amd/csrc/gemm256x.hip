@@ -58,7 +58,7 @@ __device__ __forceinline__ void x_tile_of_block(const GemmArgs& p, int ntn, int&
     }
 }
 
-template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false>
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false>
 __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, int ntn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -130,6 +130,16 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         for (int i = 0; i < (ABL == 7 ? 3 : 4); ++i) glds16(fw[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sw + i * 8 * LINE);      // (ABL 7: 7 of 8 KiB per wave and group, as 112-byte row groups would move)
     };
 
+    // Z16 (round 4): the same products on v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4 — under the chip's power envelope the 16x16
+    // f16 shape sustains 1925 TFLOP/s on random operands where 32x32x16 sustains 1622 (profiles/r04/mfma_power_probe.txt: half the accumulator
+    // registers read and written per MAC).  zacc[I][J]: 16 x 16 blocks; non-transposed D[n = 16 J + 4 qz + t][m = 16 I + c16], lane = (c16, qz).
+    f32x4 zacc[8][4];
+    if constexpr (Z16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -169,6 +179,117 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 #pragma unroll
         for (int j = 0; j < 2; ++j) { w16[j][0] = w16[j][1] = (f16x8)(f16_t)(0.002f * lane); xw[j] = (i32x8)(0x38383838 - lane); }
     }
+    if constexpr (Z16) {
+        // LDS: an f16 ring of 2 groups and an fp8 ring of 3 (the scaled MFMA takes 128 k-slots = the cross terms of TWO groups), 32 KiB each:
+        // [A 256 rows x 64 B | W 256 rows x 64 B], the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 (16 consecutive rows' reads of one
+        // logical chunk hit 64 distinct banks).  Every wave moves its own 32 rows of A and of W: 8 one-KiB pieces per group.  ONE workgroup
+        // barrier per group: behind it group s + 1 is visible and the slots of group s - 1 (f16) / s - 2 (fp8) are free.
+        constexpr int ZX = 2 * 32768;
+        const int c16 = lane & 15, qz = lane >> 4, swz = (c16 >> 2) & 3;
+        const unsigned char* za[2];
+        const unsigned char* zw[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = wave * 32 + rb * 16 + (lane >> 2);
+            const int lc = (lane & 3) ^ ((row >> 2) & 3);
+            za[rb] = A + (size_t)(m0 + row) * rsb + lc * 16;
+            zw[rb] = W + (size_t)(n0 + row) * rsb + lc * 16;
+        }
+        int xs_next = 0;                              // fp8 ring slot of the next group to stage
+        auto stage_zf = [&](int grp) {                // the f16 halves of group grp: 4 pieces per wave
+            unsigned char* fs = smem256x + (grp & 1) * 32768 + (wave * 2) * 1024;
+            const size_t o = (size_t)grp * LINE;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                glds16(za[rb] + o, fs + rb * 1024);
+                glds16(zw[rb] + o, fs + 16384 + rb * 1024);
+            }
+        };
+        auto stage_zx = [&](int grp) {                // the fp8 halves: 4 pieces per wave
+            unsigned char* xs = smem256x + ZX + xs_next * 32768 + (wave * 2) * 1024;
+            const size_t o = (size_t)grp * LINE + 64;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                glds16(za[rb] + o, xs + rb * 1024);
+                glds16(zw[rb] + o, xs + 16384 + rb * 1024);
+            }
+            xs_next = xs_next == 2 ? 0 : xs_next + 1;
+        };
+        const int zarow = (wm * 128 + c16) * 64, zwrow = 16384 + (wn * 64 + c16) * 64;
+        const int zck = (qz ^ swz) * 16;                                         // f16: logical chunk qz (k = 8 qz .. 8 qz + 7 of the group)
+        const int zx0 = ((2 * (qz & 1)) ^ swz) * 16, zx1 = ((2 * (qz & 1) + 1) ^ swz) * 16;      // fp8 parts of elements 16 (qz & 1) .. + 7 / + 8 .. + 15
+        const int sc_a = 127 - GLC_GX_SHIFT - p.act_sc, sc_w = 127 - p.mx_ws;
+        auto ldx = [&](const unsigned char* q0) __attribute__((always_inline)) {
+            const i32x4 t0 = *reinterpret_cast<const i32x4*>(q0 + zx0);
+            const i32x4 t1 = *reinterpret_cast<const i32x4*>(q0 + zx1);
+            i32x8 r;
+            r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+            return r;
+        };
+        // Per group four barrier slots (the rhythm of the 32 x 32 loop), waves 4-7 — the SIMDs' second waves — one slot behind: A1 requests of group
+        // s + 1 and the f16 fragment reads of s | B1 a_hi w_hi (32 MFMAs) | A2 requests landed; odd s: every fp8 fragment of groups s - 1 and s (all
+        // of them here, none in B2: the partner group places its next requests into the slot of s - 2 while this group is in B2) | B2 (odd s) both
+        // cross terms of the two groups, 32 MFMAs of 128 k-slots: lanes qz < 2 bring group s - 1, qz >= 2 bring s.
+        stage_zf(0); stage_zx(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // group 0 is in LDS for everyone
+        if (wm == 1) __builtin_amdgcn_s_barrier(); // the stagger
+        int xs_prev = 0, xs_cur = 0;               // fp8 ring slots of groups s - 1 and s
+        auto zstep = [&](const int s, const bool odd) __attribute__((always_inline)) {
+            // ---- A1 ----
+            if (s + 1 < ng) { stage_zf(s + 1); stage_zx(s + 1); }
+            const unsigned char* fs = smem256x + (s & 1) * 32768;
+            f16x8 za16[8], zw16[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zw16[j] = *reinterpret_cast<const f16x8*>(fs + zwrow + j * 16 * 64 + zck);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) za16[i] = *reinterpret_cast<const f16x8*>(fs + zarow + i * 16 * 64 + zck);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- B1 ----
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!VMODE) zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zw16[j], za16[i], zacc[i][j], 0, 0, 0);      // D[n][m]
+                    else zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(za16[i], zw16[j], zacc[i][j], 0, 0, 0);            // D[m][n]
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- A2 ----
+            i32x8 zxw[4], zxa[8];
+            if (odd) {
+                const unsigned char* xb = smem256x + ZX + ((qz >> 1) ? xs_cur : xs_prev) * 32768;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zxw[j] = ldx(xb + zwrow + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) zxa[i] = ldx(xb + zarow + i * 16 * 64);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- B2 ----
+            if (odd) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!VMODE) zacc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(zxw[j], zxa[i], zacc[i][j], 0, 0, 0, sc_w, 0, sc_a);
+                        else zacc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(zxa[i], zxw[j], zacc[i][j], 0, 0, 0, sc_a, 0, sc_w);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            xs_prev = xs_cur; xs_cur = xs_cur == 2 ? 0 : xs_cur + 1;
+        };
+        for (int s = 0; s < ng; s += 2) { zstep(s, false); zstep(s + 1, true); }      // (ng is even: K % 64 == 0)
+        if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
+    } else {
     const int pm = ABL ? 1 : p.prio_mode;     // (timing-only builds: the default policy)  0: no priorities; 1: MFMA phase at priority 1; 2: load phase at priority 2; 3: the late wave group at priority 1 throughout
     if (pm == 3 && wm == 1) __builtin_amdgcn_s_setprio(1);
     stage_fl(0);
@@ -252,6 +373,15 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+                        if constexpr (ABL == 8) {       // (timing only, wrong results: the same MACs, operand and accumulator registers as two v_mfma_f32_16x16x32_f16 — the shape's power)
+                            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                f32x4_ sub = {acc[i][j][8 * ks + 4 * t], acc[i][j][8 * ks + 4 * t + 1], acc[i][j][8 * ks + 4 * t + 2], acc[i][j][8 * ks + 4 * t + 3]};
+                                sub = __builtin_amdgcn_mfma_f32_16x16x32_f16(w16[j][t], a16[i][ks], sub, 0, 0, 0);
+                                acc[i][j][8 * ks + 4 * t] = sub[0]; acc[i][j][8 * ks + 4 * t + 1] = sub[1]; acc[i][j][8 * ks + 4 * t + 2] = sub[2]; acc[i][j][8 * ks + 4 * t + 3] = sub[3];
+                            }
+                        } else
                         if (!VMODE) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[j][ks], a16[i][ks], acc[i][j], 0, 0, 0);      // D[n][m]
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][ks], w16[j][ks], acc[i][j], 0, 0, 0);            // D[m][n]
                     }
@@ -277,6 +407,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     };
     for (int s = 0; s < ng; ++s) { sub(s, 0); sub(s, 1); }
     if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
+    }
     if constexpr (DIAG) {
         if (p.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {
             unsigned long long* o = p.stamps + ((size_t)(blockIdx.x >> 3) * 8 + wave) * 12;
@@ -331,6 +462,23 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float rs = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + c32].y : 1.0f;
+            if constexpr (Z16) {         // 16 x 16 blocks: J even = 16 gate features, J odd = the matching up features, same lane and register
+                const int c16 = lane & 15, qz = lane >> 4;
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const float rz = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + 16 * ip + c16].y : 1.0f;
+#pragma unroll
+                    for (int Jp = 0; Jp < 2; ++Jp) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float gt = zacc[2 * c + ip][2 * Jp][e] * rz, up = zacc[2 * c + ip][2 * Jp + 1][e] * rz;
+                            v[e] = gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
+                        }
+                        *reinterpret_cast<f32x4*>(stg + (16 * ip + c16) * 36 + 16 * Jp + 4 * qz) = v;
+                    }
+                }
+            } else
 #pragma unroll
             for (int J = 0; J < 2; ++J)
 #pragma unroll
@@ -378,7 +526,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         for (int J = 0; J < 2; ++J)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int nn = n0 + wn * 64 + 32 * J + 8 * q + 4 * h;
+                const int nn = Z16 ? n0 + wn * 64 + 32 * J + 8 * q + 4 * (lane >> 4) : n0 + wn * 64 + 32 * J + 8 * q + 4 * h;      // Z16: entries q = 0 / 2 = columns 16 (2 J + q / 2) + 4 qz ..
                 bj[J][q] = bias ? *reinterpret_cast<const f32x4*>(bias + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 cj[J][q] = (lnf && p.ln_c) ? *reinterpret_cast<const f32x4*>(p.ln_c + nn) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -438,6 +586,27 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                 if (c + 1 < 4) load_resid(c + 1, rpre, rpre_lo, rst_pre);
             }
             const float2 sm = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + c32] : make_float2(0.f, 1.f);
+            if constexpr (Z16) {         // D[n = 16 J + 4 qz + t][m = 16 I + c16] -> patch [m][n]
+                const int c16 = lane & 15, qz = lane >> 4;
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const float2 smz = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + 16 * ip + c16] : make_float2(0.f, 1.f);
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) {
+                        f32x4 v = zacc[2 * c + ip][J];
+                        if constexpr (EPI != EPI_RESID) {
+                            if (lnf) {
+                                const f32x4 cz = cj[J >> 1][2 * (J & 1)];        // (Z16: cj / bj hold the lane's four 16-column blocks, see their loads)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = smz.y * (v[r] - smz.x * cz[r]);
+                            }
+                        }
+                        v += bj[J >> 1][2 * (J & 1)];
+                        if (EPI == EPI_GELU) { const f32x2 g0 = glc_gelu2_f32((f32x2){v[0], v[1]}), g1 = glc_gelu2_f32((f32x2){v[2], v[3]}); v = (f32x4){g0[0], g0[1], g1[0], g1[1]}; }
+                        *reinterpret_cast<f32x4*>(stg + (16 * ip + c16) * 68 + 16 * J + 4 * qz) = v;
+                    }
+                }
+            } else
 #pragma unroll
             for (int J = 0; J < 2; ++J)
 #pragma unroll
@@ -650,6 +819,25 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         const int hh = (n0 + wn * 64 - 2 * p.H) >> 6;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            if constexpr (Z16) {         // D[m = 16 I + 4 qz + t][n = 16 J + c16] -> patch [n][m]
+                const int c16 = lane & 15, qz = lane >> 4;
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int J = 0; J < 4; ++J) {
+                        f32x4 v = zacc[2 * c + ip][J];
+                        const int nn = n0 + wn * 64 + 16 * J + c16;
+                        if (lnf) {
+                            const float cz = p.ln_c ? p.ln_c[nn] : 0.f;
+                            const float2* sp = p.a_stats + m0 + wm * 128 + c * 32 + 16 * ip + 4 * qz;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float2 sm = sp[r]; v[r] = sm.y * (v[r] - sm.x * cz); }
+                        }
+                        const float bz = bias ? bias[nn] : 0.f;
+                        v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+                        *reinterpret_cast<f32x4*>(stg + (16 * J + c16) * 36 + 16 * ip + 4 * qz) = v;
+                    }
+            } else
 #pragma unroll
             for (int J = 0; J < 2; ++J)
 #pragma unroll
@@ -721,8 +909,9 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     }
 }
 
-template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false>
-__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) { gemm256x_tile<EPI, VMODE, DIAG, ABL, GY>(p, n_tile0, ntn); }
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false>
+__global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) { gemm256x_tile<EPI, VMODE, DIAG, ABL, GY, Z16>(p, n_tile0, ntn); }
+constexpr int LDS_Z16 = 5 * 32768;                 // Z16: f16 ring (2 groups) + fp8 ring (3 groups)
 
 
 // Decoder QKV with the RoPE / MX-tile epilogue in ONE launch: the N-tiles of the V heads (nt >= nqk) run the transposed tile (c5: 7 + 1 N-tiles x
@@ -735,8 +924,13 @@ __global__ __launch_bounds__(512, 2) void gemm256x_qkvr_kernel(GemmArgs p, int n
     else gemm256x_tile<EPI_QKVR, true, false, 0, GY>(p, 0, ntn);
 }
 
-template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
-    if constexpr (!DIAG && ABL == 0 && !GY) {
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
+#ifdef GLC_DEVELOPER      // the 16 x 16 MFMA shapes (Z16): correct in every epilogue, -8 ... +5 % against the 32 x 32 loop — developer builds only
+    if constexpr (!DIAG && ABL == 0 && !GY && !Z16) {
+        if (a.z16 && !a.gy && a.K % 64 == 0 && !a.stamps && a.prio_mode < 4) return launch_x<EPI, VMODE, false, 0, false, true>(st, a, n_tile0, ntn);
+    }
+#endif
+    if constexpr (!DIAG && ABL == 0 && !GY && !Z16) {
         if (a.gy) {
 #ifdef GLC_DEVELOPER      // GY images (e2m3 parts with block scales): built and verified, not faster under the chip's power envelope — developer builds only
             if constexpr (EPI == EPI_BIAS && !VMODE) { if (a.stamps) return launch_x<EPI, VMODE, true, 0, true>(st, a, n_tile0, ntn); }
@@ -752,19 +946,20 @@ template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false> 
         if (a.prio_mode == 5) return a.stamps ? launch_x<EPI, VMODE, true, 5>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 5>(st, a, n_tile0, ntn);
         if (a.prio_mode == 6) return a.stamps ? launch_x<EPI, VMODE, true, 6>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 6>(st, a, n_tile0, ntn);
         if (a.prio_mode == 7) return a.stamps ? launch_x<EPI, VMODE, true, 7>(st, a, n_tile0, ntn) : launch_x<EPI, VMODE, false, 7>(st, a, n_tile0, ntn);
+        if (a.prio_mode == 8) return launch_x<EPI, VMODE, false, 8>(st, a, n_tile0, ntn);
 #endif
         if (a.stamps) return launch_x<EPI, VMODE, true>(st, a, n_tile0, ntn);
     }
     static std::atomic<unsigned> lds_ok{0};
-    constexpr int lds_bytes = GY ? LDS_GY : NSLOT * STAGE;
-    if (!glc_raise_lds_limit(gemm256x_kernel<EPI, VMODE, DIAG, ABL, GY>, lds_bytes, lds_ok)) return "gemm256x: cannot raise the dynamic LDS limit";
+    constexpr int lds_bytes = Z16 ? LDS_Z16 : GY ? LDS_GY : NSLOT * STAGE;
+    if (!glc_raise_lds_limit(gemm256x_kernel<EPI, VMODE, DIAG, ABL, GY, Z16>, lds_bytes, lds_ok)) return "gemm256x: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;
     GemmArgs b = a;
     b.n_group = 0;
     static const int prio_env = glc_dev_env("GLC_GEMM_PRIO") ? atoi(glc_dev_env("GLC_GEMM_PRIO")) : 1;      // developer A/B switch
     b.prio_mode = a.prio_mode >= 0 ? a.prio_mode : prio_env;
     if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);      // wide N: as gemm256s.hip
-    hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE, DIAG, ABL, GY>), dim3(grid), dim3(512), lds_bytes, st, b, n_tile0, ntn);
+    hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE, DIAG, ABL, GY, Z16>), dim3(grid), dim3(512), lds_bytes, st, b, n_tile0, ntn);
     return nullptr;
 }
 
@@ -909,6 +1104,8 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
     GemmArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the activation images this launch writes
+    static const bool z16_env = glc_dev_env("GLC_GEMM_Z16") && atoi(glc_dev_env("GLC_GEMM_Z16")) != 0;      // developer A/B: the 16 x 16 MFMA shapes
+    if (z16_env) a.z16 = 1;
     if (!a.act_sc) a.act_sc = glc_gx_act_sc();               // ... and the exponent of the activation rows (engine.hip act_sc)
     if (a.gx_rows <= 0) a.gx_rows = a.Mvalid > 0 ? a.Mvalid : a.Mpad;     // ... over the rows that exist (slack rows up to Mpad hold leftovers)
     if (!glc_gemm256x_supported(a, epi)) return "gemm256x: unsupported shape";

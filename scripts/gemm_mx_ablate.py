@@ -7,7 +7,7 @@ from gliclass.c_amd.config import CONFIGS
 from gliclass.c_amd import weights
 from gliclass.c_amd.engine import Engine
 e = Engine(CONFIGS["tiny"], weights.make_weights(CONFIGS["tiny"], 1), dtype="f16")
-names = {1: "full", 4: "no frag reads", 5: "no DMA", 6: "no MFMA", 7: "fp6-shaped"}
+names = {1: "full", 8: "f16 part as 16x16x32"}
 for rnd in range(2):
     for (name, M_, N, K, ep) in (("ffn2-as-bias", 65536, 768, 3072, 0), ("ffn1-as-bias", 65536, 3072, 768, 0), ("qkv-as-bias", 65536, 2304, 768, 0), ("c5-half-gate-up-as-bias", 32768, 8960, 1536, 0)):
         r = {pm: e.L.glc_debug_gemm_bench(e.h, M_, N, K, ep, 10, 100 * (1 + pm) + 9) for pm in names}

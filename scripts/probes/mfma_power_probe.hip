@@ -39,6 +39,22 @@ __global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, f
             if constexpr (KIND == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + u) & 3], b[i], c[i], 0, 0, 0);
+            } else if constexpr (KIND == 5) {        // block-scaled 16x16x128 on e4m3
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 t = {c[i][0], c[i][1], c[i][2], c[i][3]};
+                    t = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xa[(i + u) & 1], xb[i & 1], t, 0, 0, 0, 100, 0, 100);
+                    c[i][0] = t[0]; c[i][1] = t[1]; c[i][2] = t[2]; c[i][3] = t[3];
+                }
+            } else if constexpr (KIND == 4) {        // 16x16x32 f16: half the accumulator registers per MAC, twice the operand registers
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 t = {c[i][0], c[i][1], c[i][2], c[i][3]};
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(i + u) & 3], b[i], t, 0, 0, 0);
+                    c[i][0] = t[0]; c[i][1] = t[1]; c[i][2] = t[2]; c[i][3] = t[3];
+                }
             } else if constexpr (KIND == 2) {        // the same bits read as bf16
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[(i + u) & 3]), __builtin_bit_cast(bf16x8, b[i]), c[i], 0, 0, 0);
@@ -71,7 +87,7 @@ int main() {
     for (int i = 0; i < 4096; ++i) hs[i] = 12345u + 7919u * i;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    for (int kind = 0; kind < 4; ++kind)
+    for (int kind = 0; kind < 6; ++kind)
         for (int rnd = 0; rnd < 2; ++rnd) {
             hs[4096] = rnd;
             hipMemcpy(dseed, hs.data(), 4097 * 4, hipMemcpyHostToDevice);
@@ -81,15 +97,17 @@ int main() {
                 if (kind == 0) hipLaunchKernelGGL(burn<0>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 else if (kind == 1) hipLaunchKernelGGL(burn<1>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 else if (kind == 2) hipLaunchKernelGGL(burn<2>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
-                else hipLaunchKernelGGL(burn<3>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 3) hipLaunchKernelGGL(burn<3>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 4) hipLaunchKernelGGL(burn<4>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else hipLaunchKernelGGL(burn<5>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep >= 3 && ms < best) best = ms;
                 hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost);
             }
-            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : 2.0 * 32 * 32 * 64);
+            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : kind == 4 ? 2.0 * 16 * 16 * 32 : kind == 5 ? 2.0 * 16 * 16 * 128 : 2.0 * 32 * 32 * 64);
             printf("%s, %s operands: %.3f ms for %d x 16 MFMAs per wave, 2 waves per SIMD on %d CUs: %.0f TFLOP/s; shader clock %.0f MHz\n",
-                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
+                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : kind == 4 ? "v_mfma_f32_16x16x32_f16" : kind == 5 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
                    hc[1] ? (double)hc[0] * 100.0 / (double)hc[1] : 0.0);
         }
     return 0;

@@ -86,9 +86,23 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     // (both in ONE register: byte 0 = the (lo8 | hi8) value, byte 1 = the (hi8 | lo8) value, picked by the instruction's op_sel)
     const int SC = h ? (127 | ((127 - GLC_GX_SHIFT) << 8)) : ((127 - GLC_GX_SHIFT) | (127 << 8));
     // a product on MX tiles: `lh` travels as (lo8 | hi8), `hl` as (hi8 | lo8); D[row of the FIRST argument][row of the second]
+    // (ABL 4, timing only, wrong results: an f16 MFMA issued as two v_mfma_f32_16x16x32_f16 on the same operand and accumulator registers — the power
+    // of the shape, profiles/r04/mfma_power_probe.txt)
+    auto f16mm = [&](const f16x8& x, const f16x8& y, f32x16& acc, int s) __attribute__((always_inline)) {
+        if constexpr (ABL == 4) {
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int b = 8 * (s & 1) + 4 * t;
+                f32x4_ sub = {acc[b], acc[b + 1], acc[b + 2], acc[b + 3]};
+                sub = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, sub, 0, 0, 0);
+                acc[b] = sub[0]; acc[b + 1] = sub[1]; acc[b + 2] = sub[2]; acc[b + 3] = sub[3];
+            }
+        } else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, acc, 0, 0, 0);
+    };
     auto mm_lh_hl = [&](const MxFrag& lh, const MxFrag& hl, f32x16& acc) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh.f[s], hl.f[s], acc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) f16mm(lh.f[s], hl.f[s], acc, s);
         if constexpr (ABL != 1) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(lh.x[m], hl.x[m], acc, 0, 0, 0, SC, 1, SC);
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     };
     auto mm_hl_lh = [&](const MxFrag& hl, const MxFrag& lh, f32x16& acc) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl.f[s], lh.f[s], acc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) f16mm(hl.f[s], lh.f[s], acc, s);
         if constexpr (ABL != 1) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hl.x[m], lh.x[m], acc, 0, 0, 1, SC, 0, SC);
@@ -305,12 +319,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             px[4 + q] = __builtin_bit_cast(int, wl2);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o0, 0, 0, 0);      // O^T[dd][query c]
+        for (int t = 0; t < 2; ++t) f16mm(vf[t], pf[t], o0, t);      // O^T[dd][query c]
         if constexpr (ABL != 1 && ABL != 3) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o0, 0, 0, 0, SC, 1, SC);
         __builtin_amdgcn_sched_barrier(0);
         load_v(1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o1, 0, 0, 0);
+        for (int t = 0; t < 2; ++t) f16mm(vf[t], pf[t], o1, t);
         if constexpr (ABL != 1 && ABL != 3) o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o1, 0, 0, 0, SC, 1, SC);
     };
 
@@ -559,6 +573,10 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     static const bool pv16_env = glc_dev_env("GLC_ATTN_PV16") && atoi(glc_dev_env("GLC_ATTN_PV16")) != 0;
     static std::atomic<unsigned> r5{0};
     if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
+#ifdef GLC_DEVELOPER
+    static std::atomic<unsigned> r7{0};
+    if (a.variant & 1024) return go(attn_mx_kernel<NW, 4, false, true>, r7);      // bit 10: timing only, f16 MFMAs in the 16x16x32 shape
+#endif
     static std::atomic<unsigned> r6{0};
     if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
     return go(attn_mx_kernel<NW, 0, false, true>, r0);

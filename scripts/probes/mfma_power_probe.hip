@@ -14,6 +14,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
+// KIND 6 / 7: the f16 32x32x16 stream with LDS fragment traffic beside it — 1.5 / 1.0 sixteen-byte reads per lane and MFMA (what a 128 x 64 / a 128 x 128
+// wave tile of the projections reads), random data in LDS: how much of the envelope do the fragment reads take from the matrix pipe?
 template <int KIND>
 __global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, float* __restrict__ out, int iters, unsigned long long* clk) {
     const int tid = blockIdx.x * 256 + threadIdx.x;
@@ -32,10 +34,26 @@ __global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, f
         }
     f32x16 c[4];
     for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) c[i][e] = 0.f;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    if constexpr (KIND >= 6) {
+        for (int i = threadIdx.x; i < 65536 / 4; i += 256) { s = s * 1664525u + 1013904223u; reinterpret_cast<unsigned*>(lds)[i] = seed[4096] ? (s & 0x3BFF3BFFu) : 0u; }
+        __syncthreads();
+    }
+    const unsigned lbase = (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 16384;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if constexpr (KIND >= 6) {
+                constexpr int NR = KIND == 6 ? 6 : 4;        // reads per 4 MFMAs
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const f16x8 t = *reinterpret_cast<const f16x8*>(lds + ((lbase + (unsigned)(it * 4 + u) * 1024u * NR + r * 1024u) & 65535u & ~15u));
+                    if (r < 4) a[r] = t; else b[r - 4] = t;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + u) & 3], b[i], c[i], 0, 0, 0);
+            } else
             if constexpr (KIND == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + u) & 3], b[i], c[i], 0, 0, 0);
@@ -87,7 +105,7 @@ int main() {
     for (int i = 0; i < 4096; ++i) hs[i] = 12345u + 7919u * i;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    for (int kind = 0; kind < 6; ++kind)
+    for (int kind = 0; kind < 8; ++kind)
         for (int rnd = 0; rnd < 2; ++rnd) {
             hs[4096] = rnd;
             hipMemcpy(dseed, hs.data(), 4097 * 4, hipMemcpyHostToDevice);
@@ -99,15 +117,17 @@ int main() {
                 else if (kind == 2) hipLaunchKernelGGL(burn<2>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 else if (kind == 3) hipLaunchKernelGGL(burn<3>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 else if (kind == 4) hipLaunchKernelGGL(burn<4>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
-                else hipLaunchKernelGGL(burn<5>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 5) hipLaunchKernelGGL(burn<5>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 6) hipLaunchKernelGGL(burn<6>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else hipLaunchKernelGGL(burn<7>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep >= 3 && ms < best) best = ms;
                 hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost);
             }
-            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : kind == 4 ? 2.0 * 16 * 16 * 32 : kind == 5 ? 2.0 * 16 * 16 * 128 : 2.0 * 32 * 32 * 64);
+            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 || kind >= 6 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : kind == 4 ? 2.0 * 16 * 16 * 32 : kind == 5 ? 2.0 * 16 * 16 * 128 : 2.0 * 32 * 32 * 64);
             printf("%s, %s operands: %.3f ms for %d x 16 MFMAs per wave, 2 waves per SIMD on %d CUs: %.0f TFLOP/s; shader clock %.0f MHz\n",
-                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : kind == 4 ? "v_mfma_f32_16x16x32_f16" : kind == 5 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
+                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 6 ? "v_mfma_f32_32x32x16_f16 + 1.5 LDS reads per MFMA" : kind == 7 ? "v_mfma_f32_32x32x16_f16 + 1.0 LDS read per MFMA" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : kind == 4 ? "v_mfma_f32_16x16x32_f16" : kind == 5 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
                    hc[1] ? (double)hc[0] * 100.0 / (double)hc[1] : 0.0);
         }
     return 0;

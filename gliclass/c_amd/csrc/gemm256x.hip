@@ -58,8 +58,9 @@ __device__ __forceinline__ void x_tile_of_block(const GemmArgs& p, int ntn, int&
     }
 }
 
-template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false>
+template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false, bool W128 = false>
 __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, int ntn) {
+    static_assert(!W128 || Z16, "the 128 x 128 wave tile runs on the 16 x 16 MFMA shapes");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int c32 = lane & 31, h = lane >> 5;
@@ -133,12 +134,13 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     // Z16 (round 4): the same products on v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4 — under the chip's power envelope the 16x16
     // f16 shape sustains 1925 TFLOP/s on random operands where 32x32x16 sustains 1622 (profiles/r04/mfma_power_probe.txt: half the accumulator
     // registers read and written per MAC).  zacc[I][J]: 16 x 16 blocks; non-transposed D[n = 16 J + 4 qz + t][m = 16 I + c16], lane = (c16, qz).
-    f32x4 zacc[8][4];
+    constexpr int ZJ = W128 ? 8 : 4;         // W128: ONE wave per SIMD, 128 x 128 per wave (4 waves; 256 accumulator registers, the compiler keeps them in AGPRs)
+    f32x4 zacc[8][ZJ];
     if constexpr (Z16) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < ZJ; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     f32x16 acc[4][2];
 #pragma unroll
@@ -179,6 +181,86 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 #pragma unroll
         for (int j = 0; j < 2; ++j) { w16[j][0] = w16[j][1] = (f16x8)(f16_t)(0.002f * lane); xw[j] = (i32x8)(0x38383838 - lane); }
     }
+    if constexpr (W128) {
+        // The rings and the swizzle of the Z16 loop below; 4 waves, wave (wmw, wnw) owns rows 128 wmw .. and columns 128 wnw .., and moves rows
+        // [64 wave, + 64) of A and of W: 16 one-KiB pieces per group.  Lock-step, ONE barrier per group: under the power envelope idle slots are free.
+        constexpr int ZX = 2 * 32768;
+        const int wmw = wave >> 1, wnw = wave & 1;
+        const int c16 = lane & 15, qz = lane >> 4, swz = (c16 >> 2) & 3;
+        const int drow = wave * 64 + (lane >> 2), dlc = (lane & 3) ^ ((drow >> 2) & 3);
+        const unsigned char* const za = A + (size_t)(m0 + drow) * rsb + dlc * 16;
+        const unsigned char* const zw = W + (size_t)(n0 + drow) * rsb + dlc * 16;
+        int xs_next = 0;
+        auto stage_w = [&](int grp) {
+            unsigned char* fs = smem256x + (grp & 1) * 32768 + (wave * 4) * 1024;
+            unsigned char* xs = smem256x + ZX + xs_next * 32768 + (wave * 4) * 1024;
+            const size_t o = (size_t)grp * LINE;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                glds16(za + (size_t)rb * 16 * rsb + o, fs + rb * 1024);
+                glds16(zw + (size_t)rb * 16 * rsb + o, fs + 16384 + rb * 1024);
+                glds16(za + (size_t)rb * 16 * rsb + o + 64, xs + rb * 1024);
+                glds16(zw + (size_t)rb * 16 * rsb + o + 64, xs + 16384 + rb * 1024);
+            }
+            xs_next = xs_next == 2 ? 0 : xs_next + 1;
+        };
+        const int zarow = (wmw * 128 + c16) * 64, zwrow = 16384 + (wnw * 128 + c16) * 64;
+        const int zck = (qz ^ swz) * 16;
+        const int zx0 = ((2 * (qz & 1)) ^ swz) * 16, zx1 = ((2 * (qz & 1) + 1) ^ swz) * 16;
+        const int sc_a = 127 - GLC_GX_SHIFT - p.act_sc, sc_w = 127 - p.mx_ws;
+        auto ldx = [&](const unsigned char* q0) __attribute__((always_inline)) {
+            const i32x4 t0 = *reinterpret_cast<const i32x4*>(q0 + zx0);
+            const i32x4 t1 = *reinterpret_cast<const i32x4*>(q0 + zx1);
+            i32x8 r;
+            r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3]; r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+            return r;
+        };
+        stage_w(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int xs_prev = 0, xs_cur = 0;
+        auto wstep = [&](const int s, const bool odd) __attribute__((always_inline)) {
+            if (s + 1 < ng) stage_w(s + 1);
+            const unsigned char* fs = smem256x + (s & 1) * 32768;
+            f16x8 za16[8], zw16[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zw16[j] = *reinterpret_cast<const f16x8*>(fs + zwrow + j * 16 * 64 + zck);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) za16[i] = *reinterpret_cast<const f16x8*>(fs + zarow + i * 16 * 64 + zck);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (!VMODE) zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zw16[j], za16[i], zacc[i][j], 0, 0, 0);      // D[n][m]
+                    else zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(za16[i], zw16[j], zacc[i][j], 0, 0, 0);            // D[m][n]
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (odd) {
+                const unsigned char* xb = smem256x + ZX + ((qz >> 1) ? xs_cur : xs_prev) * 32768;
+                i32x8 zxw[8], zxa[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) zxw[j] = ldx(xb + zwrow + j * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) zxa[i] = ldx(xb + zarow + i * 16 * 64);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (!VMODE) zacc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(zxw[j], zxa[i], zacc[i][j], 0, 0, 0, sc_w, 0, sc_a);
+                        else zacc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(zxa[i], zxw[j], zacc[i][j], 0, 0, 0, sc_a, 0, sc_w);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            xs_prev = xs_cur; xs_cur = xs_cur == 2 ? 0 : xs_cur + 1;
+        };
+        for (int s = 0; s < ng; s += 2) { wstep(s, false); wstep(s + 1, true); }
+    } else
     if constexpr (Z16) {
         // LDS: an f16 ring of 2 groups and an fp8 ring of 3 (the scaled MFMA takes 128 k-slots = the cross terms of TWO groups), 32 KiB each:
         // [A 256 rows x 64 B | W 256 rows x 64 B], the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 (16 consecutive rows' reads of one
@@ -419,6 +501,12 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     }
 
     // ---------------- epilogue ----------------
+    // (W128: the wave's 128 x 128 as two 128 x 64 halves through the code of the 8-wave tiles — wave (wm, wn) there = (wmw, 2 wnw + ch) here)
+#pragma unroll
+    for (int ch = 0; ch < (W128 ? 2 : 1); ++ch) {
+    const int wm_outer = wm, wn_outer = wn;
+    const int wm = W128 ? (wave >> 1) : wm_outer, wn = W128 ? 2 * (wave & 1) + ch : wn_outer;
+    const int zj0 = 4 * ch;
     typedef f16_t T;
     typedef __attribute__((ext_vector_type(8))) T vec8T;
     const float* __restrict__ bias = p.bias;
@@ -472,7 +560,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float gt = zacc[2 * c + ip][2 * Jp][e] * rz, up = zacc[2 * c + ip][2 * Jp + 1][e] * rz;
+                            const float gt = zacc[2 * c + ip][zj0 + 2 * Jp][e] * rz, up = zacc[2 * c + ip][zj0 + 2 * Jp + 1][e] * rz;
                             v[e] = gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt)) * up;
                         }
                         *reinterpret_cast<f32x4*>(stg + (16 * ip + c16) * 36 + 16 * Jp + 4 * qz) = v;
@@ -593,7 +681,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                     const float2 smz = lnf ? p.a_stats[m0 + wm * 128 + c * 32 + 16 * ip + c16] : make_float2(0.f, 1.f);
 #pragma unroll
                     for (int J = 0; J < 4; ++J) {
-                        f32x4 v = zacc[2 * c + ip][J];
+                        f32x4 v = zacc[2 * c + ip][zj0 + J];
                         if constexpr (EPI != EPI_RESID) {
                             if (lnf) {
                                 const f32x4 cz = cj[J >> 1][2 * (J & 1)];        // (Z16: cj / bj hold the lane's four 16-column blocks, see their loads)
@@ -825,7 +913,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                 for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
                     for (int J = 0; J < 4; ++J) {
-                        f32x4 v = zacc[2 * c + ip][J];
+                        f32x4 v = zacc[2 * c + ip][zj0 + J];
                         const int nn = n0 + wn * 64 + 16 * J + c16;
                         if (lnf) {
                             const float cz = p.ln_c ? p.ln_c[nn] : 0.f;
@@ -899,6 +987,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
             __builtin_amdgcn_wave_barrier();
         }
     }
+    }
     if constexpr (DIAG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.stamps && blockIdx.x < 64 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {
@@ -912,6 +1001,11 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false>
 __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) { gemm256x_tile<EPI, VMODE, DIAG, ABL, GY, Z16>(p, n_tile0, ntn); }
 constexpr int LDS_Z16 = 5 * 32768;                 // Z16: f16 ring (2 groups) + fp8 ring (3 groups)
+// W128: four waves, one per SIMD, 512 registers each
+template <int EPI, bool VMODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_kernel(GemmArgs p, int n_tile0, int ntn) {
+    gemm256x_tile<EPI, VMODE, false, 0, false, true, true>(p, n_tile0, ntn);
+}
 
 
 // Decoder QKV with the RoPE / MX-tile epilogue in ONE launch: the N-tiles of the V heads (nt >= nqk) run the transposed tile (c5: 7 + 1 N-tiles x
@@ -926,6 +1020,17 @@ __global__ __launch_bounds__(512, 2) void gemm256x_qkvr_kernel(GemmArgs p, int n
 
 template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
 #ifdef GLC_DEVELOPER      // the 16 x 16 MFMA shapes (Z16): correct in every epilogue, -8 ... +5 % against the 32 x 32 loop — developer builds only
+    if constexpr (!DIAG && ABL == 0 && !GY && !Z16) {
+        if (a.w128 && !a.gy && a.K % 64 == 0 && !a.stamps && a.prio_mode < 4) {       // one wave per SIMD, 128 x 128 per wave
+            static std::atomic<unsigned> lds_okw{0};
+            if (!glc_raise_lds_limit(gemm256w_kernel<EPI, VMODE>, LDS_Z16, lds_okw)) return "gemm256x: cannot raise the dynamic LDS limit";
+            GemmArgs b = a;
+            b.n_group = 0;
+            if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);
+            hipLaunchKernelGGL((gemm256w_kernel<EPI, VMODE>), dim3((a.Mpad / TM) * ntn), dim3(256), LDS_Z16, st, b, n_tile0, ntn);
+            return nullptr;
+        }
+    }
     if constexpr (!DIAG && ABL == 0 && !GY && !Z16) {
         if (a.z16 && !a.gy && a.K % 64 == 0 && !a.stamps && a.prio_mode < 4) return launch_x<EPI, VMODE, false, 0, false, true>(st, a, n_tile0, ntn);
     }
@@ -1104,6 +1209,8 @@ bool glc_gemm256x_supported(const GemmArgs& a, int epi) {
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
     GemmArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the activation images this launch writes
+    static const bool w128_env = glc_dev_env("GLC_GEMM_W128") && atoi(glc_dev_env("GLC_GEMM_W128")) != 0;      // developer A/B: one wave per SIMD, 128 x 128 wave tiles
+    if (w128_env) a.w128 = 1;
     static const bool z16_env = glc_dev_env("GLC_GEMM_Z16") && atoi(glc_dev_env("GLC_GEMM_Z16")) != 0;      // developer A/B: the 16 x 16 MFMA shapes
     if (z16_env) a.z16 = 1;
     if (!a.act_sc) a.act_sc = glc_gx_act_sc();               // ... and the exponent of the activation rows (engine.hip act_sc)

@@ -338,7 +338,12 @@ def profile_mode(hipl, h, step, sync, cfg, B, S, Cn, dtype, seqs_per_s_one_gpu, 
                 # this mode costs mfma_per_product MFMAs, i.e. x3 self-inflicted work in the default mode — over the f16 peak.  The
                 # number that counts against the north star is e2e_frac (algorithmic FLOPs).
                 mfma_units_whole_forward=round(mpp_fwd, 3),
-                executed_mfma_whole_forward_frac=round(executed * mpp_fwd / peak, 4), per_kernel=per)
+                executed_mfma_whole_forward_frac=round(executed * mpp_fwd / peak, 4),
+                # context, not a claim: what the matrix pipe sustains under the chip's power envelope on random operands (a committed probe result —
+                # profiles/r04/mfma_power_probe.txt: nothing but MFMAs on registers; the nominal `peak` above is reached on all-zero operands only)
+                envelope=dict(f16_mfma_random_operands_tflops=1614.0, fp8_scaled_mfma_random_operands_tflops=4292.0,
+                              source="profiles/r04/mfma_power_probe.txt (scripts/probes/mfma_power_probe.hip)"),
+                per_kernel=per)
 
 
 def prob_err(a, b):

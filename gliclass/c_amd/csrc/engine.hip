@@ -134,6 +134,7 @@ struct glc_engine {
     std::map<int, int2*> otabs;                // Sp -> byte offsets of the PQ / PK rows per relative distance (band kernel, 16-bit)
     std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
     std::map<int, std::pair<void*, int4*>> mx2tabs;   // Sp -> (idx16, tinfo) of attention_mx2.hip; (null, null): this table keeps the band kernel
+    bool mxs = false;                          // MX attention on the role-split kernel (attention_mxs.hip: a matrix wave + a softmax wave per SIMD; bit-identical to attention_mx.hip): GLC_ATTN_MXS, glc_debug_set_mxs
     bool mx2 = false;                          // MX attention on the bucket-space kernel (attention_mx2.hip; needs its tables) instead of the band kernel (attention_mx.hip): opt-in
                                                // (GLC_ATTN_MX2=1, glc_debug_set_mx2) — measured 4-5 % slower at c3
     // last forward
@@ -751,7 +752,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         a.otab = e->otabs[Sp];
         if (mxa) { a.PK = w.PKm; a.PQ = w.PQm; e->last_mx_attn = true; a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second; }
         const bool mxa2 = mxa && e->mx2 && a.idx16 && a.tinfo;      // bucket-space kernel (round 4) when this length's table has the structure it needs
-        { Prof p(e, PC_ATTN); KCHK(mxa2 ? glc_launch_attention_mx2(st, a) : mxa ? glc_launch_attention_mx(st, a) : launch_band(a), false); }
+        { Prof p(e, PC_ATTN); KCHK(mxa2 ? glc_launch_attention_mx2(st, a) : mxa ? (e->mxs ? glc_launch_attention_mxs(st, a) : glc_launch_attention_mx(st, a)) : launch_band(a), false); }
         if (e->debug_stop == 10 * l + 1) return true;
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
@@ -1037,6 +1038,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
         if (const char* av = glc_dev_env("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
         if (const char* av = glc_dev_env("GLC_DEC_ROPE_EPI")) e->dec_rope_epi = atoi(av) != 0;      // developer A/B switch
+        if (const char* av = glc_dev_env("GLC_ATTN_MXS")) e->mxs = atoi(av) != 0;         // developer A/B switch: the role-split kernel (attention_mxs.hip) / the band kernel (attention_mx.hip)
         if (const char* av = glc_dev_env("GLC_ATTN_MX2")) e->mx2 = atoi(av) != 0;         // developer A/B switch: 1 = the bucket-space kernel (attention_mx2.hip)
     }
     if (const char* gv = glc_dev_env("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
@@ -1414,6 +1416,7 @@ int glc_debug_fp8_range_retries(const glc_engine* e) { return e ? e->fp8_retries
 int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_off ? 1 : 0) : -1; }
 int glc_debug_activation_exponent(const glc_engine* e) { return e ? e->act_sc : 1; }
 long long glc_debug_mx_weight_bytes(const glc_engine* e) { return e ? (long long)e->mx_bytes : -1; }
+int glc_debug_set_mxs(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mxs = on != 0; return 0; }
 int glc_debug_set_mx2(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx2 = on != 0; return 0; }
 
 int glc_engine_set_length_buckets(glc_engine* e, int max_groups) {
@@ -1862,7 +1865,8 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     }
     const bool mxk2 = mxk && (variant & 8192) != 0;           // bit 13: the bucket-space MX kernel (attention_mx2.hip)
     if (mxk2 && !(a.idx16 && a.tinfo)) { set_err("attn_bench: no mx2 tables for this length"); return -1.f; }
-    auto launch = [&]() -> const char* { return mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
+    const bool mxs = mxk && (variant & 32768) != 0;          // bit 15: the role-split MX kernel (attention_mxs.hip)
+    auto launch = [&]() -> const char* { return mxs ? glc_launch_attention_mxs(st, a) : mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
     for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);
     for (int i = 0; i < iters; ++i) launch();

@@ -200,6 +200,8 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
 // Workgroup-shared band kernel on MX tiles (attention_mx.hip; the attention of the MX pipeline): Qh / Kh / Vt / PQ / PK are MX tiles
 // (glc_layout.h), CTX is written as GX rows; otab is the split-unit offset table.
 const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a);
+// Round 5: the same contract and bit-identical results, role-split workgroup — a matrix wave and a softmax wave per SIMD (attention_mxs.hip).
+const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a);
 // Round 4: the same operands and outputs, position terms in bucket (delta) space, one independent wave per query tile (attention_mx2.hip).
 // glc_mx2_build_tables: the kernel's two tables from the distance -> delta table of a padded length; false = this table does not have the
 // structure the kernel needs (the caller keeps glc_launch_attention_mx).

@@ -144,6 +144,10 @@ class Engine:
         """exponent of the MX pipeline's activation rows: 0, or -5 once a forward left the fp8 range (the guard's first answer)"""
         return int(self.L.glc_debug_activation_exponent(self.h))
 
+    def set_mxs(self, on):
+        """MX attention on the role-split kernel (attention_mxs.hip) or on the band kernel (attention_mx.hip); same results bit for bit"""
+        self.L.glc_debug_set_mxs(self.h, int(bool(on)))
+
     def set_mx2(self, on):
         """MX attention on the bucket-space kernel (attention_mx2.hip) or on the band kernel (attention_mx.hip)"""
         self.L.glc_debug_set_mx2(self.h, int(bool(on)))

@@ -1915,9 +1915,22 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
             (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
             AttnArgs as = a; as.stamps = dbuf;
-            const char* m = mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
+            const char* m = mxs ? glc_launch_attention_mxs(st, as) : mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
             (void)hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(ns);
+            if (!m && mxs && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                // role-split kernel: waves 0-3 matrix, 4-7 softmax; segments as stamped in attention_mxs.hip
+                double sm[10] = {0}, sx[10] = {0};
+                for (size_t i = 0; i < 64 * 8; ++i) for (int k = 0; k < 10; ++k) ((i & 7) < 4 ? sm : sx)[k] += (double)hs[i * 10 + k];
+                const double nm = sm[9] > 0 ? sm[9] : 1, nx = sx[9] > 0 ? sx[9] : 1;
+                double tm = 0, tx = 0;
+                for (int k = 0; k < 8; ++k) { tm += sm[k]; tx += sx[k]; }
+                fprintf(stderr, "[attn_mxs stamps] per step, matrix wave (%.0f steps): request wait + DMA issue %.0f | first half: gather, operand reads, MFMA issue, stores %.0f | stores landed + barrier A %.0f | "
+                                "second half: K DMA, c2p store, P.V, next K fragments, row requests %.0f | barrier B %.0f | total %.0f | s_memtime clock %.0f MHz\n",
+                        nm, sm[0] / nm, sm[1] / nm, sm[2] / nm, sm[3] / nm, sm[4] / nm, tm / nm, sm[8] / (64 * 4) / 10.0);
+                fprintf(stderr, "[attn_mxs stamps] per step, softmax wave (%.0f steps): barrier A %.0f | S + gather + max + exp %.0f | barrier B %.0f | sums + split + stores %.0f | total %.0f\n",
+                        nx, sx[0] / nx, sx[1] / nx, sx[2] / nx, sx[3] / nx, tx / nx);
+            } else
             if (!m && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                 double s[10] = {0};
                 for (size_t i = 0; i < 64 * 8; ++i) for (int k = 0; k < 10; ++k) s[k] += (double)hs[i * 10 + k];

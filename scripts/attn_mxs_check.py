@@ -1,6 +1,6 @@
 """Developer tool (GPU): the role-split MX attention (attention_mxs.hip) against the band kernel (attention_mx.hip) on the SAME MX tiles —
-the context rows must be IDENTICAL (same products, same accumulation order) — then interleaved timing on the first shape.
-usage: attn_mxs_check.py   env: GLC_SHAPES (BxS,...), GLC_CONFIG, GLC_REPS"""
+the context rows must agree to rounding (same products; only the leaving p2c block is summed in another order) — then interleaved timing on the first shape.
+usage: attn_mxs_check.py [stamps 0/1: needs make DEV=1]   env: GLC_SHAPES (BxS,...), GLC_CONFIG, GLC_REPS"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,7 @@ from gliclass.c_amd.engine import Engine
 cfg = CONFIGS[os.environ.get("GLC_CONFIG", "base")]
 shapes = [tuple(int(x) for x in s.split("x")) for s in os.environ.get("GLC_SHAPES", "64x1024,8x512,3x192,2x64,5x640,2x1536").split(",")]
 reps = int(os.environ.get("GLC_REPS", 4))
+stamps = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 e = Engine.from_spec(cfg, f"synthetic:{cfg.name}:42", dtype="f32")
 e.set_length_buckets(1)
 e.set_group_split(2)
@@ -40,8 +41,11 @@ for (B, S) in shapes:
         same = np.array_equal(a[valid], b[valid])
         d = np.abs(a - b)[valid]
         nz = int((d != 0).sum())
-        bad += 0 if same else 1
-        print(f"B={B} S={S} ragged={ragged}: identical {same}  (differing elements {nz} of {d.size}, max |diff| {d.max():.3e}, finite {np.isfinite(b[valid]).all()})", flush=True)
+        rel = d.max() / max(np.abs(a[valid]).max(), 1e-30)
+        # the same products in the same order except the leaving p2c block (16 x 16 MFMA shapes sum their k-steps in another order): <= ~2e-5 of the rows' scale
+        ok = bool(np.isfinite(b[valid]).all()) and rel <= 5e-5
+        bad += 0 if ok else 1
+        print(f"B={B} S={S} ragged={ragged}: identical {same}  (differing elements {nz} of {d.size}, max |diff| {d.max():.3e} = {rel:.2e} of the rows' max; {'OK' if ok else 'FAIL'})", flush=True)
 B, S = shapes[0]
 ids, mask, _ = synth.make_inputs(cfg, B, S, 8, seed=3)
 e.L.glc_debug_set_stop(e.h, 1)
@@ -50,7 +54,7 @@ flops = B * S * (4.0 * S * cfg.hidden + 4.0 * P * cfg.hidden)
 for rep in range(reps):
     for v in [128, 128 | 32768]:
         cs = (ctypes.c_double * 2)()
-        ms = e.L.glc_debug_attn_bench(e.h, 20, v, 0, cs)
+        ms = e.L.glc_debug_attn_bench(e.h, 20, v, stamps if rep == 0 else 0, cs)
         print(f"variant {v}: {ms:.4f} ms  {flops/ms/1e9:7.1f} TF (algorithmic)", flush=True)
 e.L.glc_debug_set_stop(e.h, -1)
 e.close()

@@ -95,7 +95,7 @@ template <int N> struct IC { static constexpr int value = N; };
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_mxs[];
 
 // DIAG: s_memtime stamps at the phase boundaries of a step, summed per wave (glc_debug_attn_bench prints them; developer builds only).
-template <bool DIAG>
+template <bool DIAG, int XPRIO = 0>
 __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = wave & 3;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
         // =============================== softmax wave ===============================
         const float* __restrict__ kb = a.kbias + (size_t)b * Sp;
         const int kfirst = a.kfirst[b];
+        if (XPRIO == 1) __builtin_amdgcn_s_setprio(1);
         const int foff = 8 * h;
         float m = -3.0e38f, l = 0.f;
         float one_f = 1.0f;
@@ -286,6 +287,8 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
     }
 
     // =============================== matrix wave ===============================
+    if (XPRIO == 2) __builtin_amdgcn_s_setprio(1);          // (developer A/B: XPRIO 1 = the softmax wave at priority 1; 2 / 3 = the matrix wave at priority 1 / 3)
+    if (XPRIO == 3) __builtin_amdgcn_s_setprio(3);
     // e8m0 scales of the block-scaled MFMA (attention_mx.hip)
     const int SC = h ? (127 | ((127 - GLC_GX_SHIFT) << 8)) : ((127 - GLC_GX_SHIFT) | (127 << 8));
     auto mm_lh_hl = [&](const MxFrag& lh, const MxFrag& hl, f32x16& acc) __attribute__((always_inline)) {
@@ -545,8 +548,7 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) kf.x[m] = cat8(*reinterpret_cast<const i32x4*>(kc_ + 4096 + m * 2048 + lane * 16), *reinterpret_cast<const i32x4*>(kc_ + 4096 + m * 2048 + 1024 + lane * 16));
         }
-        f32x16 sacc, cacc;
-        int iq = 0;
+        f32x16 sacc;
         if constexpr (BAND) {
             const unsigned char* ktile = k_ring + (kt & 1) * TILEB;
             int rbo = 63 - rr_base;
@@ -559,11 +561,9 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
             f32x16 bacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-            __builtin_amdgcn_sched_barrier(0);
             mm_p_hl_lh_f16(pq, kf, bacc);                     // p2c block of image slot jm, f16 part: every operand is in registers — covers the LDS latency of the gather and of K's MX steps
-            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(bacc), "+v"(sacc));        // (order: the gathered values are waited for BEHIND those four MFMAs)
             mm_lh_hl(kf, qf, sacc);                           // S^T = K Q^T + c2p
-            __builtin_amdgcn_sched_barrier(0);
             // the leaving block's quarter: A = PQ rows from the px area, B = K(kt) key slots, both in the 16 x 16 operand layouts
             f16x8 af[2], bf[2];
 #pragma unroll
@@ -573,27 +573,20 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
             }
             mm_p_hl_lh_x(pq, kf, bacc);                       // ... its cross terms
             __builtin_amdgcn_sched_barrier(0);
-            store_s(sacc);
             f32x4q qacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) qacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s2], bf[s2], qacc, 0, 0, 0);
+            store_s(sacc);
             __builtin_amdgcn_sched_barrier(0);
             {
                 const i32x8 ax = cat8(*reinterpret_cast<const i32x4*>(px_area + 4096 + qx_a), *reinterpret_cast<const i32x4*>(px_area + 4096 + 1024 + qx_a));
                 const i32x8 bx = cat8(*reinterpret_cast<const i32x4*>(ktile + 4096 + qx_b), *reinterpret_cast<const i32x4*>(ktile + 4096 + 1024 + qx_b));
-                iq = (w + kt + 1) & 3;                        // the query tile whose NEW c2p block L(kt + 1) this wave's PK block is
                 qacc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ax, bx, qacc, 0, 0, 0, 127 - GLC_GX_SHIFT, 0, 127);
             }
             __builtin_amdgcn_sched_barrier(0);
-            MxFrag qi;
-            k_tile(q_static + iq * TILEB, qi);
             const int jm = (w + kt) & 3;                      // image slot of this wave's block
             band_store(p2c_img + c * LROWP + 32 * jm, bacc);
             *reinterpret_cast<f32x4q*>(p2c_img + (16 * qb + l15) * LROWP + 32 * NQ + 16 * qa + 4 * lg) = qacc;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
-            mm_p_lh_hl(pk, qi, cacc);                         // c2p of tile iq: [rr reversed][query]; stored to iq's ring after A
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[i] = cq;
@@ -607,9 +600,56 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
         stamp(2);                                                        // M seg 2: stores landed + barrier A
         // ---------------- second half ----------------
         if (kt + 2 < nkt) dma_k(kt + 2, kt & 1);                         // (K(kt)'s slot: every wave holds its fragments since A(kt))
-        if constexpr (BAND) band_store(reinterpret_cast<float*>(smem_mxs + OFF_RING) + (size_t)iq * 32 * LROW + c * LROW + XR, cacc);      // (tile iq gathered this half's victim before A(kt))
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt > 0) pv((kt - 1) & 1);
+        // P(kt - 1), V^T(kt - 1) and the rescale flag / factors are requested first; the c2p block of step kt + 1 — operands: this wave's PK
+        // block (registers) and the Q tile it belongs to this step (static area) — is computed under their latency
+        const unsigned char* vtile = v_ring + ((kt - 1) & 1) * TILEB;
+        const int flv = *flag;
+        const float alpha = f_buf[lane];
+        f16x8 pf[2], vf[2], vg[2];
+        i32x8 px, vx, vy;
+        pf[0] = *reinterpret_cast<const f16x8*>(p_buf + lane * 16);
+        pf[1] = *reinterpret_cast<const f16x8*>(p_buf + 1024 + lane * 16);
+        px = cat8(*reinterpret_cast<const i32x4*>(p_buf + 2048 + lane * 16), *reinterpret_cast<const i32x4*>(p_buf + 3072 + lane * 16));
+        vf[0] = *reinterpret_cast<const f16x8*>(vtile + lane * 16);
+        vf[1] = *reinterpret_cast<const f16x8*>(vtile + 1024 + lane * 16);
+        vx = cat8(*reinterpret_cast<const i32x4*>(vtile + 2048 + lane * 16), *reinterpret_cast<const i32x4*>(vtile + 3072 + lane * 16));
+        vg[0] = *reinterpret_cast<const f16x8*>(vtile + 4096 + lane * 16);
+        vg[1] = *reinterpret_cast<const f16x8*>(vtile + 4096 + 1024 + lane * 16);
+        vy = cat8(*reinterpret_cast<const i32x4*>(vtile + 4096 + 2048 + lane * 16), *reinterpret_cast<const i32x4*>(vtile + 4096 + 3072 + lane * 16));
+        if constexpr (BAND) {
+            const int iq = (w + kt + 1) & 3;                  // the query tile whose NEW c2p block L(kt + 1) this wave's PK block is
+            MxFrag qi;
+            k_tile(q_static + iq * TILEB, qi);
+            f32x16 cacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cacc[i] = 0.f;
+            mm_p_lh_hl(pk, qi, cacc);                         // [rr reversed][query]
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt > 0) {
+                if (__builtin_amdgcn_readfirstlane(flv)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o0, 0, 0, 0);      // O^T[dd][query c]
+                o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o0, 0, 0, 0, SC, 1, SC);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            band_store(reinterpret_cast<float*>(smem_mxs + OFF_RING) + (size_t)iq * 32 * LROW + c * LROW + XR, cacc);      // (tile iq gathered this half's victim before A(kt))
+        } else if (kt > 0) {
+            if (__builtin_amdgcn_readfirstlane(flv)) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t], pf[t], o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vx, px, o0, 0, 0, 0, SC, 1, SC);
+        }
+        if (kt > 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vg[t], pf[t], o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vy, px, o1, 0, 0, 0, SC, 1, SC);
+        }
         __builtin_amdgcn_sched_barrier(0);
         {                                                                // K(kt + 1)'s f16 units: published by A(kt) (after the last tile: a stale slot, unused)
             const unsigned char* kn = k_ring + ((kt + 1) & 1) * TILEB;
@@ -702,6 +742,15 @@ const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a_in) {
     }
 #endif
     if (a.stamps) return "attention(mxs): the stamped build exists in developer builds only (make DEV=1)";
+#ifdef GLC_DEVELOPER
+    {
+        static std::atomic<unsigned> rp1{0}, rp2{0}, rp3{0};
+        const int xp = a.variant & 3;
+        if (xp == 1) { if (!glc_raise_lds_limit(attn_mxs_kernel<false, 1>, MXS_LDS, rp1)) return "lds"; hipLaunchKernelGGL((attn_mxs_kernel<false, 1>), dim3(nqb * bh8), dim3(512), MXS_LDS, st, a); return nullptr; }
+        if (xp == 2) { if (!glc_raise_lds_limit(attn_mxs_kernel<false, 2>, MXS_LDS, rp2)) return "lds"; hipLaunchKernelGGL((attn_mxs_kernel<false, 2>), dim3(nqb * bh8), dim3(512), MXS_LDS, st, a); return nullptr; }
+        if (xp == 3) { if (!glc_raise_lds_limit(attn_mxs_kernel<false, 3>, MXS_LDS, rp3)) return "lds"; hipLaunchKernelGGL((attn_mxs_kernel<false, 3>), dim3(nqb * bh8), dim3(512), MXS_LDS, st, a); return nullptr; }
+    }
+#endif
     if (!glc_raise_lds_limit(attn_mxs_kernel<false>, MXS_LDS, r0)) return "attention(mxs): cannot raise the dynamic LDS limit";
     hipLaunchKernelGGL(attn_mxs_kernel<false>, dim3(nqb * bh8), dim3(512), MXS_LDS, st, a);
     return nullptr;

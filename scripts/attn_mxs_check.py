@@ -52,9 +52,9 @@ e.L.glc_debug_set_stop(e.h, 1)
 e.forward(ids, mask)
 flops = B * S * (4.0 * S * cfg.hidden + 4.0 * P * cfg.hidden)
 for rep in range(reps):
-    for v in [128, 128 | 32768]:
+    for v in [128, 128 | 32768] + [128 | 32768 | int(x) for x in os.environ.get('GLC_XV', '').split(',') if x]:
         cs = (ctypes.c_double * 2)()
-        ms = e.L.glc_debug_attn_bench(e.h, 20, v, stamps if rep == 0 else 0, cs)
+        ms = e.L.glc_debug_attn_bench(e.h, 20, v, stamps if (rep == 0 and (v & 3) == 0) else 0, cs)
         print(f"variant {v}: {ms:.4f} ms  {flops/ms/1e9:7.1f} TF (algorithmic)", flush=True)
 e.L.glc_debug_set_stop(e.h, -1)
 e.close()

@@ -594,6 +594,9 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
             mm_lh_p_hl(kf, pq, sacc);                         // + K_k . PQ[d*] (same for every query column)
             store_s(sacc);
         }
+        MxFrag qi;                                                       // the Q tile this wave's PK block belongs to this step: static data, read BEFORE the barrier —
+        const int iq = (w + kt + 1) & 3;                                 // the c2p MFMAs behind A(kt) start on operands that are in registers
+        if constexpr (BAND) k_tile(q_static + iq * TILEB, qi);
         stamp(1);                                                        // M seg 1: ring gather, operand reads, MFMA issue, stores issued
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // stores landed (this half's V^T pieces stay in flight)
         __builtin_amdgcn_s_barrier();                                    // A(kt)
@@ -617,9 +620,6 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
         vg[1] = *reinterpret_cast<const f16x8*>(vtile + 4096 + 1024 + lane * 16);
         vy = cat8(*reinterpret_cast<const i32x4*>(vtile + 4096 + 2048 + lane * 16), *reinterpret_cast<const i32x4*>(vtile + 4096 + 3072 + lane * 16));
         if constexpr (BAND) {
-            const int iq = (w + kt + 1) & 3;                  // the query tile whose NEW c2p block L(kt + 1) this wave's PK block is
-            MxFrag qi;
-            k_tile(q_static + iq * TILEB, qi);
             f32x16 cacc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) cacc[i] = 0.f;

@@ -100,6 +100,44 @@ def test_mx2_bucket_space_attention_vs_band_kernel_and_oracle():
         eng.close()
 
 
+def test_mxs_role_split_attention_vs_band_kernel_and_oracle():
+    """Round 5: the role-split MX attention (attention_mxs.hip: a matrix wave and a softmax wave per SIMD, position blocks resident in
+    registers, the leaving p2c block as 16 x 16 quarters; opt-in) against the band kernel of the same engine.  Same products in the same
+    order except the leaving block (16 x 16 MFMA shapes sum their k-steps in another order): the probabilities must agree to 2e-5, one
+    row per long shape also with the CPU oracle.  Shapes: the log buckets and both saturated ends (S >= 1000), a workgroup with two
+    inactive query tiles (Sp % 128 == 64), a single key tile, ragged rows (the key-length cut and the early exit of fully padded blocks)."""
+    import oracle_c
+    from gliclass.c_amd import synth, weights
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    cfg = CONFIGS["base"]
+    eng = Engine.from_spec(cfg, "synthetic:base:42", dtype="f32")
+    w = None
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+    try:
+        eng.set_length_buckets(1)
+        for (B, S, Cn, ragged) in ((64, 1024, 8, False), (100, 320, 8, True), (33, 1000, 5, True), (17, 2048, 8, True), (1024, 64, 1, False), (24, 704, 3, True), (40, 192, 4, True)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=B + S, ragged=ragged)
+            eng.set_mxs(False)
+            band = eng.forward(ids, mask)
+            assert eng.last_mx_attention(), (B, S)
+            eng.set_mxs(True)
+            got = eng.forward(ids, mask)
+            assert eng.last_mx_attention() and np.isfinite(got).all(), (B, S)
+            d = float(np.abs(sig(got) - sig(band)).max())
+            assert d <= 2e-5, (B, S, Cn, d)
+            if S >= 1000:
+                if w is None:
+                    w = weights.make_weights(cfg, 42)
+                b = B // 2
+                n = int(mask[b].sum())
+                ref = oracle_c.forward(cfg, w, ids[b:b + 1, :n], mask[b:b + 1, :n])
+                assert np.abs(sig(got[b:b + 1, :ref.shape[1]]) - sig(ref)).max() <= 3e-4, (B, S)
+        eng.set_mxs(False)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("gain", [12.0, 40.0, 400.0])
 def test_fp8_range_guard_encoder_outlier_channel(gain):
     """VERDICT r3 item 4 / ADVICE r3 (medium): the MX operand images carry e4m3 parts with exponent 0, so an activation beyond 448 saturates

@@ -589,8 +589,12 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
             else if (lean32) hipLaunchKernelGGL((attn_band_kernel<float, true>), grid, block, dyn, st, a);
             else hipLaunchKernelGGL((attn_band_kernel<float, false>), grid, block, dyn, st, a);
         } else if (a.stamps) {
+#ifdef GLC_DEVELOPER
             if (dtype != GLC_DT_F16) return "attention: the stamped build exists for f16 only";
             hipLaunchKernelGGL((attn_band_kernel<f16_t, false, true>), grid, block, dyn, st, a);   // rolled loop: room for the stamp registers
+#else
+            return "attention: the stamped build exists in developer builds only (make DEV=1)";
+#endif
         } else if (dtype == GLC_DT_BF16) {
             if (unroll6) hipLaunchKernelGGL((attn_band_kernel<bf16_t, true>), grid, block, dyn, st, a);
             else hipLaunchKernelGGL((attn_band_kernel<bf16_t, false>), grid, block, dyn, st, a);

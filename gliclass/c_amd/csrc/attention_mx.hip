@@ -566,19 +566,19 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
         hipLaunchKernelGGL(kern, dim3(nqb * bh8), dim3(64 * NW), lds, st, a);
         return nullptr;
     };
-    static std::atomic<unsigned> r0{0}, r1{0}, r2{0}, r4{0};
+    static std::atomic<unsigned> r0{0};
+#ifdef GLC_DEVELOPER      // stamped, timing-only (WRONG results) and measurement builds: developer libraries only
+    static std::atomic<unsigned> r1{0}, r2{0}, r4{0}, r5{0}, r6{0}, r7{0};
     if (a.stamps) return go(attn_mx_kernel<NW, 0, true, true>, r4);
     if (a.variant & 256) return go(attn_mx_kernel<NW, 1>, r1);
     if (a.variant & 512) return go(attn_mx_kernel<NW, 2>, r2);
     static const bool pv16_env = glc_dev_env("GLC_ATTN_PV16") && atoi(glc_dev_env("GLC_ATTN_PV16")) != 0;
-    static std::atomic<unsigned> r5{0};
     if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
-#ifdef GLC_DEVELOPER
-    static std::atomic<unsigned> r7{0};
-    if (a.variant & 1024) return go(attn_mx_kernel<NW, 4, false, true>, r7);      // bit 10: timing only, f16 MFMAs in the 16x16x32 shape
-#endif
-    static std::atomic<unsigned> r6{0};
+    if (a.variant & 65536) return go(attn_mx_kernel<NW, 4, false, true>, r7);    // bit 16: timing only, f16 MFMAs in the 16x16x32 shape
     if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
+#else
+    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
+#endif
     return go(attn_mx_kernel<NW, 0, false, true>, r0);
 }
 }  // namespace
@@ -592,7 +592,7 @@ const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a_in) {
     if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
     // workgroup shape (kernel header): 4 waves x two workgroups per CU by default; GLC_ATTN_MX_NW=8 or AttnArgs::variant bit 11: 8 waves x one (bit 10: 4)
     static const int nw_env = glc_dev_env("GLC_ATTN_MX_NW") ? atoi(glc_dev_env("GLC_ATTN_MX_NW")) : 4;
-    const int nw = (a.variant & 1024) ? 4 : (a.variant & 2048) ? 8 : nw_env;
+    const int nw = (a.variant & 1024) ? 4 : (a.variant & 2048) ? 8 : nw_env;     // (bits 10 / 11 choose the workgroup shape and nothing else)
     return nw == 8 ? launch_mx<8>(st, a) : launch_mx<4>(st, a);
 }
 

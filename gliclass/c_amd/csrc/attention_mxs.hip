@@ -297,12 +297,6 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(lh.x[m], hl.x[m], acc, 0, 0, 0, SC, 1, SC);
     };
-    auto mm_hl_lh = [&](const MxFrag& hl, const MxFrag& lh, f32x16& acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl.f[s], lh.f[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hl.x[m], lh.x[m], acc, 0, 0, 1, SC, 0, SC);
-    };
 
     // the same products with the position block (PFrag) as first (A) operand: c2p = PK (lo8 | hi8) x Q, p2c = PQ (hi8 | lo8) x K
     auto mm_p_lh_hl = [&](const PFrag& lh, const MxFrag& hl, f32x16& acc) __attribute__((always_inline)) {
@@ -310,12 +304,6 @@ __global__ __launch_bounds__(512, 2) void attn_mxs_kernel(AttnArgs a) {
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lh.f[s], hl.f[s], acc, 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(lh.xa[m], lh.xb[m]), hl.x[m], acc, 0, 0, 0, SC, 1, SC);
-    };
-    auto mm_p_hl_lh = [&](const PFrag& hl, const MxFrag& lh, f32x16& acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl.f[s], lh.f[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(hl.xa[m], hl.xb[m]), lh.x[m], acc, 0, 0, 1, SC, 0, SC);
     };
     auto mm_p_hl_lh_f16 = [&](const PFrag& hl, const MxFrag& lh, f32x16& acc) __attribute__((always_inline)) {
 #pragma unroll

@@ -603,9 +603,13 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
     if (a.stamps && !(dtype == GLC_DT_F32 && a.split && !(a.variant & 57))) return "attention(wg): the stamped build exists for the split-f16 8-wave kernel only";
     if (dtype == GLC_DT_F32) {
         if (!a.split) return "attention(wg): the fp32 mode runs this kernel on split-f16 units only";
+#ifdef GLC_DEVELOPER      // stamped and timing-only (WRONG results) builds: developer libraries only
         if (a.stamps) return launch_wg<float, true, 8, false, false, false, true>(st, a);
-        if (a.prec) return launch_wg<float, true, 8, false, false, false, false, true>(st, a);      // precision-budget build
         if (a.variant & 64) return launch_wg<float, true, 8, false, false, false, false, false, 2>(st, a);      // timing-only: two MFMAs per product
+#else
+        if (a.stamps || (a.variant & 64)) return "attention(wg): stamped and timing-only builds exist in developer builds only (make DEV=1)";
+#endif
+        if (a.prec) return launch_wg<float, true, 8, false, false, false, false, true>(st, a);      // precision-budget build
         // half-tile stagger: measured same-box 1.42-1.51 vs 1.44-1.45 ms per launch at c3 — no gain, off by default (GLC_ATTN_STAG=1 / variant bit 4)
         static const bool stag_default = glc_dev_env("GLC_ATTN_STAG") != nullptr && atoi(glc_dev_env("GLC_ATTN_STAG")) != 0;
         if (a.variant & 8) return launch_wg<float, true, 8, true>(st, a);

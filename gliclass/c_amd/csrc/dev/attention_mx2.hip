@@ -24,9 +24,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "glc_common.h"
-#include "glc_kernels.h"
-#include "glc_layout.h"
+#include "../glc_common.h"
+#include "../glc_kernels.h"
+#include "../glc_layout.h"
 
 namespace {
 

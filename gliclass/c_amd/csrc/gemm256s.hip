@@ -696,7 +696,11 @@ static bool use_full_lines() {
 template <typename T, int EPI, bool VMODE, bool GS = false, bool PD = false, bool FL = false, bool DIAG = false> const char* launch_e(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
     if constexpr (GS && !PD && !FL) { if (a.prec) return launch_e<T, EPI, VMODE, GS, true, false>(st, a, n_tile0, ntn); }
     if constexpr (!PD && !FL) { if (use_full_lines() && (GS || a.K % 64 == 0)) return launch_e<T, EPI, VMODE, GS, false, true>(st, a, n_tile0, ntn); }
+#ifdef GLC_DEVELOPER      // the stamped build: developer libraries only
     if constexpr (FL && !DIAG && EPI == EPI_BIAS && !VMODE) { if (a.stamps) return launch_e<T, EPI, VMODE, GS, false, true, true>(st, a, n_tile0, ntn); }
+#else
+    if (a.stamps) return "gemm256s: the stamped build exists in developer builds only (make DEV=1)";
+#endif
     static std::atomic<unsigned> lds_ok{0};        // per device: several engines of one process may sit on different GPUs
     if (!glc_raise_lds_limit(gemm256s_kernel<T, EPI, VMODE, GS, PD, FL, DIAG>, NSLOT * STAGE, lds_ok)) return "gemm256s: cannot raise the dynamic LDS limit";
     const int grid = (a.Mpad / TM) * ntn;

@@ -137,9 +137,18 @@ const char* glc_launch_gs_absmax(hipStream_t st, const void* gs, size_t n, unsig
 const char* glc_launch_gs_to_gx(hipStream_t st, const void* gs, void* gx, size_t n, int sc);
 // GY rows (glc_common.h: e2m3 parts with block scales, gy_row_bytes(K) per row): plain fp32 rows -> GY (A order / worder != 0: W order), the
 // projection weights from their split-f16 copies (W order), and back to fp32 (A order: x = hi + lo)
+#ifdef GLC_DEVELOPER      // GY rows (e2m3 cross terms with block scales: csrc/dev/gemm256x_dev.hip) — developer builds only
 const char* glc_launch_to_gy(hipStream_t st, const float* src, void* dst, size_t rows, int K, int worder);
 const char* glc_launch_gs_to_gy(hipStream_t st, const void* gs, void* dst, size_t rows, int K);
+#else
+inline const char* glc_launch_to_gy(hipStream_t, const float*, void*, size_t, int, int) { return "GY rows exist in developer builds only (make DEV=1)"; }
+inline const char* glc_launch_gs_to_gy(hipStream_t, const void*, void*, size_t, int) { return "GY rows exist in developer builds only (make DEV=1)"; }
+#endif
+#ifdef GLC_DEVELOPER
 const char* glc_launch_gy_to_f32(hipStream_t st, const void* src, float* dst, size_t rows, int K);
+#else
+inline const char* glc_launch_gy_to_f32(hipStream_t, const void*, float*, size_t, int) { return "GY rows exist in developer builds only (make DEV=1)"; }
+#endif
 #ifndef GLC_GX_SHIFT
 #define GLC_GX_SHIFT 11                     // GX rows: lo8 = e4m3((x - hi) * 2^(GLC_GX_SHIFT + sc)) (glc_common.h)
 #endif
@@ -202,12 +211,18 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
 const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a);
 // Round 5: the same contract and bit-identical results, role-split workgroup — a matrix wave and a softmax wave per SIMD (attention_mxs.hip).
 const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a);
-// Round 4: the same operands and outputs, position terms in bucket (delta) space, one independent wave per query tile (attention_mx2.hip).
+// Round 4: the same operands and outputs, position terms in bucket (delta) space, one independent wave per query tile (csrc/dev/attention_mx2.hip:
+// measured 4-6 % slower than the band kernel — a DEVELOPER kernel since round 5, not in the product library).
 // glc_mx2_build_tables: the kernel's two tables from the distance -> delta table of a padded length; false = this table does not have the
 // structure the kernel needs (the caller keeps glc_launch_attention_mx).
-const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a);
 #include <vector>
+#ifdef GLC_DEVELOPER
+const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a);
 bool glc_mx2_build_tables(int Sp, int P, const int32_t* dtab, std::vector<unsigned char>& idx16, std::vector<int4>& tinfo);
+#else
+inline const char* glc_launch_attention_mx2(hipStream_t, const AttnArgs&) { return "attention(mx2): the bucket-space kernel exists in developer builds only (make DEV=1)"; }
+inline bool glc_mx2_build_tables(int, int, const int32_t*, std::vector<unsigned char>&, std::vector<int4>&) { return false; }
+#endif
 // position tables at load: split-f16 units (Q / K layout, ntiles tiles of 32 rows x 64 columns) -> MX tiles; hl: (hi8 | lo8) order (PQ), else (lo8 | hi8) (PK)
 const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat = nullptr);   // sat: fp8 range guard counter (glc_common.h)
 

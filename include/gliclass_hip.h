@@ -187,6 +187,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
 int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, int mode, double* out);
 /* Developer microbenchmark of the band attention kernel on the workspace of the last forward (see engine.hip). */
 float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, double* checksum);
+int glc_debug_is_developer_build(void);                  /* 1: built with make DEV=1 (developer kernels, stamps, GLC_* switches); 0: the product library */
 
 const glc_model_config* glc_engine_config(const glc_engine* e);
 int glc_engine_dtype(const glc_engine* e);

@@ -99,8 +99,9 @@ struct glc_engine {
     // fp8 range guard of the MX pipeline (glc_common.h gx_range_note): device counter of activation elements beyond the e4m3 range, its value after the
     // last checked forward, a pinned host slot for the device-resident path; forwards repeated on the split-f16 kernels because they counted
     // any; consecutive such forwards (the model has outlier channels: after kFp8Sticky of them the engine leaves the MX pipeline for good)
-    unsigned* d_gxsat = nullptr; unsigned gxsat_seen = 0; unsigned* h_gxsat = nullptr;
+    unsigned* d_gxsat = nullptr; unsigned gxsat_seen[2] = {0, 0}; unsigned* h_gxsat = nullptr;      // two words: [0] activation rows (GX images, exponent act_sc), [1] Q / K / V MX tiles (exponent 0)
     int fp8_retries = 0, fp8_streak = 0; bool fp8_sticky_off = false, fp8_device_pending = false;
+    int device_invalid = 0;                    // a device-resident forward since the last glc_engine_sync left the fp8 range (1: rows only, 2: tiles): its logits are not valid
     // Activation exponent of the MX pipeline's GX rows (hi8 = e4m3(x 2^act_sc), glc_common.h): 0 until a forward leaves the e4m3 range (|x| > 448);
     // the guard's FIRST answer is then kActScLow = -5 for this engine (rows hold |x| up to 14336, elements below 0.5 keep fewer hi8 bits — their
     // cross terms are 2^-16 of a unit product either way) and the forward is repeated on the MX pipeline; only what still leaves the range
@@ -215,10 +216,10 @@ bool upload_as(glc_engine* e, const float* src, size_t n, void* dst, float* stag
 constexpr int kFp8Sticky = 2;
 bool init_range_guard(glc_engine* e) {
     if (e->d_gxsat) return true;
-    e->d_gxsat = (unsigned*)dmalloc(e, sizeof(unsigned), false);
-    if (!e->d_gxsat || hipMemset(e->d_gxsat, 0, sizeof(unsigned)) != hipSuccess) { set_err("range-guard counter alloc failed"); return false; }
-    if (hipHostMalloc((void**)&e->h_gxsat, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { e->h_gxsat = nullptr; set_err("range-guard host slot alloc failed"); return false; }
-    *e->h_gxsat = 0;
+    e->d_gxsat = (unsigned*)dmalloc(e, 2 * sizeof(unsigned), false);
+    if (!e->d_gxsat || hipMemset(e->d_gxsat, 0, 2 * sizeof(unsigned)) != hipSuccess) { set_err("range-guard counter alloc failed"); return false; }
+    if (hipHostMalloc((void**)&e->h_gxsat, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { e->h_gxsat = nullptr; set_err("range-guard host slot alloc failed"); return false; }
+    e->h_gxsat[0] = e->h_gxsat[1] = 0;
     return true;
 }
 bool ensure_capacity(glc_engine* e, int B, int S, int C) {
@@ -415,8 +416,8 @@ const char* launch_gemm128(glc_engine* e, int dt, int epi, GemmArgs a) {
 // MX pipeline: the GX copies of the projection weights (hi f16 | fp8 parts, glc_common.h; each tensor with the fp8 exponent its largest
 // magnitude allows), made on the device from the split-f16 (group-split) copies by the FIRST forward that takes the pipeline — an engine
 // whose forwards never reach the 256-tile pipeline (the reference's own batches of 8 short texts) never pays their memory.
-bool build_mx_weights(glc_engine* e) {
-    if (e->mx_ready) return true;
+// (the body; `made` collects every pointer slot it fills so that build_mx_weights can undo a partial build)
+static bool build_mx_weights_impl(glc_engine* e, std::vector<void**>& made) {
     unsigned* d_bits = (unsigned*)e->splitk_ws;          // (scratch: the split-K workspace is idle between launches)
     if (!d_bits) { set_err("MX weights: no scratch"); return false; }
     auto copy = [&](const void* gs, size_t n, void*& dst, int& ws) -> bool {
@@ -430,6 +431,7 @@ bool build_mx_weights(glc_engine* e) {
         ws = glc_gx_weight_exponent(mxv);
         dst = dmalloc(e, n * sizeof(float), false);
         if (!dst) return false;
+        made.push_back(&dst);
         KCHK(glc_launch_gs_to_gx(e->stream, gs, dst, n, ws), false);
         e->mx_bytes += n * sizeof(float);
         return true;
@@ -442,14 +444,16 @@ bool build_mx_weights(glc_engine* e) {
         // of the GX copy (and a copy of the bias) go into the order glc_rope_perm128 names — 32-row blocks 1 and 2 of the head trade places
         const bool rope_epi = e->dec_rope_epi && c.head_dim == 128 && c.heads % 2 == 0 && c.kv_heads % 2 == 0;
         void* tmp = nullptr;
+        struct TmpGuard { glc_engine* e; void*& p; ~TmpGuard() { if (p) { (void)hipStreamSynchronize(e->stream); dfree(e, p); p = nullptr; } } } tmp_guard{e, tmp};      // (every exit path)
         const size_t blk = (size_t)32 * H * sizeof(float);        // 32 GX rows
         if (rope_epi) { tmp = dmalloc(e, blk, false); if (!tmp) return false; }
         for (auto& w : e->dlayers) {
             if (!copy(w.Wqkvf, NQKV * H, w.Wqkvf_x, w.ws_qkvf) || !copy(w.Wo, H * NQ, w.Wo_x, w.ws_o) ||
-                !copy(w.Wguf, 2 * I * H, w.Wguf_x, w.ws_guf) || !copy(w.Wd, H * I, w.Wd_x, w.ws_d)) { dfree(e, tmp); return false; }
+                !copy(w.Wguf, 2 * I * H, w.Wguf_x, w.ws_guf) || !copy(w.Wd, H * I, w.Wd_x, w.ws_d)) return false;
             if (!rope_epi) continue;
             w.bqkv_p = (float*)dmalloc(e, NQKV * sizeof(float), false);
-            if (!w.bqkv_p) { dfree(e, tmp); return false; }
+            if (!w.bqkv_p) return false;
+            made.push_back(reinterpret_cast<void**>(&w.bqkv_p));
             HIPCHK(hipMemcpyAsync(w.bqkv_p, w.bqkv, NQKV * sizeof(float), hipMemcpyDeviceToDevice, e->stream), false);
             for (int hd = 0; hd < c.heads + c.kv_heads; ++hd) {
                 char* r1 = (char*)w.Wqkvf_x + ((size_t)hd * 128 + 32) * H * sizeof(float);
@@ -461,7 +465,6 @@ bool build_mx_weights(glc_engine* e) {
                 HIPCHK(hipMemcpyAsync(w.bqkv_p + hd * 128 + 64, w.bqkv + hd * 128 + 32, 32 * sizeof(float), hipMemcpyDeviceToDevice, e->stream), false);
             }
         }
-        if (tmp) { HIPCHK(hipStreamSynchronize(e->stream), false); dfree(e, tmp); }
     } else {
         for (size_t l = 0; l < e->layers.size(); ++l) {
             LayerW& w = e->layers[l];
@@ -471,8 +474,25 @@ bool build_mx_weights(glc_engine* e) {
         }
     }
     HIPCHK(hipStreamSynchronize(e->stream), false);
-    e->mx_ready = true;
     return true;
+}
+
+// The GX copies of the projection weights (+0.4 / 1.4 / 5.2 GB for base / large / the Qwen2-1.5B shape), built by the first forward that takes the
+// MX pipeline.  A failure (out of memory, most likely) must not fail that forward, leak per call or leave a layer half converted:
+// whatever this call allocated is freed, the pointers are cleared, and the engine stays on the split-f16 kernels (as GLICLASS_MX=0) from then on.
+bool build_mx_weights(glc_engine* e) {
+    if (e->mx_ready) return true;
+    if (!e->mx_built) return false;
+    std::vector<void**> made;
+    if (build_mx_weights_impl(e, made)) { e->mx_ready = true; return true; }
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipGetLastError();
+    for (void** slot : made) { dfree(e, *slot); *slot = nullptr; }
+    e->mx_bytes = 0;
+    e->mx_built = false;
+    e->mx = false;
+    fprintf(stderr, "gliclass: the MX weight copies could not be built (%s); this engine keeps the split-f16 arithmetic (as GLICLASS_MX=0)\n", glc_last_error());
+    return false;
 }
 
 // The head after the row gather: the two FeaturesProjectors (Linear -> GELU -> Linear; text rows [0, rt) and class rows [rt, rt + rc)
@@ -569,7 +589,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     e->last_lnf = rnf;
     // MX pipeline (round 3, as the encoder's): GX rows + gemm256x for the four projections of every layer; attention stays on split units
     bool mx = rnf && e->mx && e->mx_built && e->prec_mask == 0;
-    if (mx && !build_mx_weights(e)) return false;
+    if (mx && !build_mx_weights(e)) mx = false;          // (no copies: this and every later forward stay on the split-f16 kernels)
     for (int l = 0; mx && l < L; ++l) mx = e->dlayers[l].Wqkvf_x && e->dlayers[l].Wo_x && e->dlayers[l].Wguf_x && e->dlayers[l].Wd_x;
     e->last_mx = mx;
     const bool mxa = mx && mfma && e->mx_attn;      // round 4: the attention of the MX pipeline on MX tiles too (decoder_mx.hip)
@@ -703,7 +723,7 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
     // full layers — a_hi*w_hi as f16 MFMAs, both cross terms as one block-scaled fp8 MFMA.  Needs the LayerNorm fold on every layer.
     bool mx = gs && e->mx && e->mx_built && e->ln_fused && e->prec_mask == 0 && c.layers >= 2;
     for (int l = 0; mx && l < c.layers; ++l) mx = e->layers[l].W1f && (l == 0 || e->layers[l].Wqkvf);       // (the folded split-f16 copies the GX copies are made from)
-    if (mx && !build_mx_weights(e)) return false;
+    if (mx && !build_mx_weights(e)) mx = false;          // (no copies: this and every later forward stay on the split-f16 kernels)
     for (int l = 0; mx && l < c.layers; ++l) mx = e->layers[l].W1f_x && e->layers[l].Wqkv_x && e->layers[l].Wo_x && e->layers[l].W2_x && (l == 0 || e->layers[l].Wqkvf_x);
     e->last_mx = mx;
     e->last_mx_attn = false;
@@ -1086,6 +1106,8 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         std::vector<float> wq((size_t)H * H), bq(H), bqkv(3 * (size_t)H);
         e->layers.resize(L);
         bool lok = true;
+        float ln_bound = 0.f;
+        for (int i = 0; i < H; ++i) ln_bound = fmaxf(ln_bound, fabsf(tensors[1][i]) * sqrtf((float)H) + fabsf(tensors[2][i]));      // the embedding LayerNorm
         for (int l = 0; l < L && lok; ++l) {
             const float* const* t = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * l;
             LayerW& w = e->layers[l];
@@ -1108,6 +1130,9 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
             w.bo = upload_f32(e, t[7], H); w.ln1g = upload_f32(e, t[8], H); w.ln1b = upload_f32(e, t[9], H);
             w.b1 = upload_f32(e, t[11], I); w.b2 = upload_f32(e, t[13], H);
             w.ln2g = upload_f32(e, t[14], H); w.ln2b = upload_f32(e, t[15], H);
+            for (int i = 0; i < H; ++i) {       // (proactive fp8 range guard, below: the largest element a normalised row of this layer can hold)
+                ln_bound = fmaxf(ln_bound, fmaxf(fabsf(t[8][i]) * sqrtf((float)H) + fabsf(t[9][i]), fabsf(t[14][i]) * sqrtf((float)H) + fabsf(t[15][i])));
+            }
             if (!w.bqkv || !w.bo || !w.ln1g || !w.ln1b || !w.b1 || !w.b2 || !w.ln2g || !w.ln2b) { lok = false; break; }
             if (hipStreamSynchronize(e->stream) != hipSuccess) { set_err("sync failed"); lok = false; break; }   // bqkv host buffer is reused
             if (e->w_presplit && dtype == GLC_F32) {
@@ -1182,12 +1207,21 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                     if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PQs, w.PQm, nh * (P / 32), 1, e->d_gxsat);
                     if (!pm && (hipMemcpyAsync(&seen, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)) pm = "MX position tables: readback failed";
                     if (pm) { set_err(pm); lok = false; }
-                    else if (seen != e->gxsat_seen) { e->gxsat_seen = seen; dfree(e, w.PKm); dfree(e, w.PQm); w.PKm = w.PQm = nullptr; }
+                    else if (seen != e->gxsat_seen[0]) { e->gxsat_seen[0] = seen; dfree(e, w.PKm); dfree(e, w.PQm); w.PKm = w.PQm = nullptr; }
                 }
                 if (!lok) break;
             }
         }
         if (!lok) { fail(); break; }
+        // Proactive fp8 range guard: the activation rows of the MX pipeline are LayerNorm outputs (and raw sums built from
+        // them); an element of a normalised row is at most |gamma| sqrt(H) + |beta|.  A checkpoint whose gains put that bound beyond e4m3's
+        // 448 (outlier channels) starts with the activation exponent the reactive guard would reach after one repeated forward — no request
+        // pays the 2-3x repeat.  (The bound is the worst case of one spiked row; the reactive guard stays in place behind it.)
+        if (e->mx_built && ln_bound > 448.0f && e->act_sc == 0) {
+            e->act_sc = kActScLow;
+            fprintf(stderr, "gliclass: LayerNorm gains of this checkpoint allow activations up to %.0f (beyond the fp8 range of the MX operand images, 448); "
+                            "this engine's activation rows carry exponent %d (|x| up to %d) from the start\n", ln_bound, kActScLow, 448 << -kActScLow);
+        }
         const float* const* ht = tensors + GLC_TENSORS_FIXED + GLC_TENSORS_PER_LAYER * L;
         bool hok = true;
         for (int i = 0; i < 8 && hok; ++i) {
@@ -1219,6 +1253,17 @@ void glc_engine_destroy(glc_engine* e) {
 }
 
 // One padded batch: H2D, launch sequence, D2H of logits [B, c_alloc] and per-row class-token counts.  Caller holds e->mu.
+// The stream's work is complete and a device-resident forward's counter copy sits in the pinned slot: compare, remember the verdict for
+// glc_engine_sync / glc_engine_device_forward_valid, and give the guard's answer (rows only: exponent kActScLow; tiles, or rows again: split-f16).
+static void settle_device_range_check(glc_engine* e) {
+    e->fp8_device_pending = false;
+    const bool rows = e->h_gxsat[0] != e->gxsat_seen[0], tiles = e->h_gxsat[1] != e->gxsat_seen[1];
+    e->gxsat_seen[0] = e->h_gxsat[0]; e->gxsat_seen[1] = e->h_gxsat[1];
+    if (!rows && !tiles) return;
+    if (rows && !tiles && e->act_sc == 0) { e->act_sc = kActScLow; e->device_invalid = 1; }
+    else { e->fp8_sticky_off = true; e->device_invalid = 2; }
+}
+
 static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, int S, float* logits, int c_alloc, int* cnt) {
     if (!ensure_capacity(e, B, S, c_alloc)) return -1;
     const size_t nb = (size_t)B * S * sizeof(int64_t);
@@ -1239,19 +1284,27 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
         ~Restore() { e->ln_fused = fused; e->mx = mx; }
     } restore{e, e->ln_fused, e->mx};
     if (e->fp8_sticky_off) e->mx = false;
-    unsigned sat_now = e->gxsat_seen;
+    // (a device-resident forward that has not been through glc_engine_sync yet: settle its range check first — this forward's own
+    //  counter readings would otherwise make the pinned copy look stale and glc_engine_sync report a range error that never happened)
+    if (e->fp8_device_pending) {
+        HIPCHK(hipStreamSynchronize(e->stream), -1);
+        settle_device_range_check(e);
+    }
+    unsigned sat_now[2] = {e->gxsat_seen[0], e->gxsat_seen[1]};
     bool tried_unfused = false, tried_split = false, tried_low = false;
     for (int attempt = 0; attempt < 4; ++attempt) {      // at most: MX, MX with exponent kActScLow, split-f16, norms unfused
         if (!run_forward(e, e->d_ids, e->d_mask, B, S, c_alloc, e->d_logits)) return -1;
         HIPCHK(hipMemcpyAsync(cnt, e->cls_cnt, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, e->stream), -1);
         if (c_alloc > 0) HIPCHK(hipMemcpyAsync(logits, e->d_logits, (size_t)B * c_alloc * sizeof(float), hipMemcpyDeviceToHost, e->stream), -1);
-        HIPCHK(hipMemcpyAsync(&sat_now, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), -1);
+        HIPCHK(hipMemcpyAsync(sat_now, e->d_gxsat, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), -1);
         HIPCHK(hipStreamSynchronize(e->stream), -1);
         bool finite = true;
         for (size_t i = 0, n = (size_t)B * (c_alloc > 0 ? c_alloc : 0); i < n && finite; ++i) finite = isfinite(logits[i]);
-        const bool sat = sat_now != e->gxsat_seen;
-        e->gxsat_seen = sat_now;
-        if (sat && e->last_mx && e->act_sc == 0 && !tried_low) {      // first answer: activation rows with exponent kActScLow, still on the MX pipeline (kept for this engine)
+        // the two words of the guard: activation rows (their exponent can be lowered) and Q / K / V tiles (exponent 0: only the split kernels help)
+        const bool sat_rows = sat_now[0] != e->gxsat_seen[0], sat_tiles = sat_now[1] != e->gxsat_seen[1];
+        const bool sat = sat_rows || sat_tiles;
+        e->gxsat_seen[0] = sat_now[0]; e->gxsat_seen[1] = sat_now[1];
+        if (sat_rows && !sat_tiles && e->last_mx && e->act_sc == 0 && !tried_low) {      // first answer: activation rows with exponent kActScLow, still on the MX pipeline (kept for this engine)
             tried_low = true;
             e->act_sc = kActScLow;
             e->fp8_retries++;
@@ -1438,7 +1491,7 @@ int glc_engine_forward_device(glc_engine* e, const void* d_ids, const void* d_ma
     if (!ok) return -1;
     // fp8 range guard (forward_one): a device-resident forward cannot be repeated behind the caller's back — the counter travels to a pinned
     // slot behind it, and glc_engine_sync reports a forward that left the range (and moves the engine to the split arithmetic)
-    if (e->last_mx) { HIPCHK(hipMemcpyAsync(e->h_gxsat, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), -1); e->fp8_device_pending = true; }
+    if (e->last_mx) { HIPCHK(hipMemcpyAsync(e->h_gxsat, e->d_gxsat, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream), -1); e->fp8_device_pending = true; }
     return 0;
 }
 
@@ -1448,23 +1501,34 @@ int glc_engine_sync(glc_engine* e) {
     HIPCHK(hipStreamSynchronize(e->stream), -1);
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->profile) prof_collect(e);
-    if (e->fp8_device_pending) {
-        e->fp8_device_pending = false;
-        if (*e->h_gxsat != e->gxsat_seen) {
-            e->gxsat_seen = *e->h_gxsat;
-            if (e->act_sc == 0) {
-                e->act_sc = kActScLow;
-                set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images (|x| > 448): its logits are "
-                        "not valid; this engine's activation rows now carry exponent -5 (|x| up to 14336) — run the forward again");
-            } else {
-                e->fp8_sticky_off = true;
-                set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images: its logits are "
-                        "not valid; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0) — run the forward again");
-            }
-            return -1;
-        }
+    if (e->fp8_device_pending) settle_device_range_check(e);
+    if (e->device_invalid) {
+        const int what = e->device_invalid;
+        e->device_invalid = 0;
+        if (what == 1)
+            set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images (|x| > 448): its logits are "
+                    "not valid; this engine's activation rows now carry exponent -5 (|x| up to 14336) — run the forward again");
+        else
+            set_err("sync: a device-resident forward since the last sync had activations beyond the fp8 range of the MX operand images: its logits are "
+                    "not valid; this engine now runs the split-f16 arithmetic (as GLICLASS_MX=0) — run the forward again");
+        return -1;
     }
     return 0;
+}
+
+/* For callers of glc_engine_forward_device that wait for the engine's stream by other means than glc_engine_sync (hipStreamSynchronize,
+ * an event, a consumer queued on the stream is NOT enough: it reads the logits before anybody has looked at the counter): once the stream's
+ * work is complete, 1 = the logits of every device-resident forward since the last check are valid, 0 = one of them left the fp8 range of
+ * the MX operand images — its logits are not valid (NaN-poisoned operand images), the engine has changed its arithmetic as glc_engine_sync
+ * would have, run it again; -1 = error.  The stream must be idle: this call does not wait. */
+int glc_engine_device_forward_valid(glc_engine* e) {
+    if (!e) { set_err("device_forward_valid: null engine"); return -1; }
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (hipStreamQuery(e->stream) != hipSuccess) { set_err("device_forward_valid: the engine's stream still has work queued — wait for it first (or call glc_engine_sync)"); return -1; }
+    if (e->fp8_device_pending) settle_device_range_check(e);
+    const int bad = e->device_invalid;
+    e->device_invalid = 0;
+    return bad ? 0 : 1;
 }
 
 void* glc_device_malloc(glc_engine* e, size_t bytes) {
@@ -1646,7 +1710,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
             hipMalloc((void**)&bias, N * sizeof(float)) || hipMalloc((void**)&tmp, nmax * sizeof(float))) { set_err("gemm_bench: alloc failed"); break; }
         std::vector<float> h(nmax);
         unsigned s = 12345u;
-        const char* zenv = getenv("GLC_BENCH_DATA");       // developer: "zero" = all-zero operands, "const" = one value everywhere (how much of the time is the power envelope?)
+        const char* zenv = glc_dev_env("GLC_BENCH_DATA");       // developer: "zero" = all-zero operands, "const" = one value everywhere (how much of the time is the power envelope?)
         for (size_t i = 0; i < nmax; ++i) { s = s * 1664525u + 1013904223u; h[i] = zenv && zenv[0] == 'z' ? 0.f : zenv && zenv[0] == 'c' ? 0.37f : ((float)(s >> 8) / 8388608.f - 1.f) * 0.5f; }
         if (hipMemcpy(tmp, h.data(), nmax * sizeof(float), hipMemcpyHostToDevice)) { set_err("gemm_bench: copy failed"); break; }
         if (gsb) {      // fp32 values, split in place into the group-split image (or the GX image)

@@ -268,7 +268,7 @@ __device__ __forceinline__ void gx_store8(unsigned char* row, int e0, const floa
 // 8 consecutive values of one row of an MX tile (decoder_mx.hip; the decoder QKV epilogue of gemm256x.hip): the 16-byte f16 piece and the two
 // 8-byte fp8 pieces (hl: (hi8 | lo8), else (lo8 | hi8)); exponent 0
 __device__ __forceinline__ void store_mx8(unsigned char* f16_dst, unsigned char* mx_dst, const float (&v)[8], bool hl, unsigned* sat) {
-    gx_range_note(v, 1.0f, sat);
+    gx_range_note(v, 1.0f, sat ? sat + 1 : nullptr);      // (MX tiles count in the guard's SECOND word: their exponent is fixed, lowering the rows' exponent cannot help them)
     gs_h8 hi;
     u32x2 l8, h8;
     gx_split8(v, 1.0f, 1.0f / (float)(1 << GLC_GX_SHIFT), hi, l8, h8);

@@ -96,10 +96,22 @@ int glc_engine_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, i
 
 /* Device-resident forward (bench / pipelined callers): d_ids, d_mask int64 [B,S] and d_logits
  * f32 [B,C] are device pointers on this engine's device; C = number of class-token slots to score.
- * Enqueues on the engine stream and returns; call glc_engine_sync() to wait. */
+ * Enqueues on the engine stream and returns; call glc_engine_sync() to wait.
+ *
+ * CONTRACT (fp8 range guard of the MX pipeline, the default arithmetic of large fp32-mode forwards): the operand images of that pipeline
+ * hold e4m3 parts; an activation beyond their range (|x| > 448) has no image, and from 464 on its parts are NaN.  A host-buffer forward
+ * (glc_engine_forward) notices and repeats itself behind the caller's back; a device-resident forward cannot.  Its d_logits are valid
+ * only once glc_engine_sync() has returned 0 — or glc_engine_device_forward_valid() has returned 1 for callers that wait by other means.
+ * glc_engine_sync() returning -1 with "... run the forward again" means: the logits of the forward(s) since the last sync are NOT valid,
+ * the engine has already changed its arithmetic (first answer: activation rows at exponent -5, |x| up to 14336, still on the MX pipeline;
+ * second answer, or outliers in Q / K / V: the split-f16 kernels for good, as GLICLASS_MX=0), and the same forward has to be enqueued again.
+ * At most two such repeats per engine lifetime.  Consumers queued on the stream BEHIND the forward (an RCCL all-gather, a D2H copy) read
+ * whatever the forward wrote: check before trusting them.  Engines created with GLICLASS_MX=0, 16-bit engines and small forwards never
+ * take the MX pipeline and never report this. */
 int glc_engine_forward_device(glc_engine* e, const void* d_ids, const void* d_mask, int B, int S, int C,
                               void* d_logits);
 int glc_engine_sync(glc_engine* e);
+int glc_engine_device_forward_valid(glc_engine* e);      /* 1 valid / 0 repeat the forward / -1 error; the stream must be idle (see above) */
 
 /* Exact last-layer pruning (default on; env GLICLASS_PRUNE_LAST=0 disables): the final encoder layer computes
  * Q / attention output / FFN only for the rows the head reads ([CLS] + class tokens).  Logits are unchanged. */
@@ -168,7 +180,8 @@ int glc_debug_set_precision_mask(glc_engine* e, int mask);
  * stream beyond the f16 operand range; engine.hip forward_one). */
 int glc_debug_range_retries(const glc_engine* e);
 /* fp8 range guard of the MX pipeline: host-buffer forwards repeated on the split-f16 kernels because an activation left the e4m3 range of the
- * operand images (|x| > 448); 1 once the engine has left the MX pipeline for good (two such forwards in a row, or one seen by glc_engine_sync) */
+ * operand images (|x| > 448); 1 once the engine has left the MX pipeline for good (two such host-buffer forwards in a row; a device-resident forward
+ * whose Q / K / V tiles left the range, or a second one after the activation exponent was already lowered — glc_engine_sync's second answer) */
 int glc_debug_fp8_range_retries(const glc_engine* e);
 int glc_debug_fp8_range_sticky(const glc_engine* e);
 /* ... and the exponent the engine's activation rows carry: 0, or -5 once a forward left the range (the guard's first answer: rows that hold

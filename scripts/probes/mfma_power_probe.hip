@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256) void burn(const unsigned* __restrict__ seed, f
                     const i32x4 ia = {xa[(i + u) & 1][0], xa[(i + u) & 1][1], xa[(i + u) & 1][2], xa[(i + u) & 1][3]}, ib = {xb[i & 1][0], xb[i & 1][1], xb[i & 1][2], xb[i & 1][3]};
                     c[i] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(ia, ib, __builtin_bit_cast(i32x16, c[i]), 0, 0, 0));
                 }
+            } else if constexpr (KIND == 8) {        // round 5: the block-scaled MFMA on e2m3 (fp6) operands — 6 of the 8 operand registers, half the cycles of e4m3
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[(i + u) & 1], xb[i & 1], c[i], 2, 2, 0, 100, 0, 100);
+            } else if constexpr (KIND == 9) {        // ... and on e2m1 (fp4): 4 of the 8 operand registers
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[(i + u) & 1], xb[i & 1], c[i], 4, 4, 0, 100, 0, 100);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[(i + u) & 1], xb[i & 1], c[i], 0, 0, 0, 100, 0, 100);
@@ -105,7 +111,7 @@ int main() {
     for (int i = 0; i < 4096; ++i) hs[i] = 12345u + 7919u * i;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
-    for (int kind = 0; kind < 8; ++kind)
+    for (int kind = 0; kind < 10; ++kind)
         for (int rnd = 0; rnd < 2; ++rnd) {
             hs[4096] = rnd;
             hipMemcpy(dseed, hs.data(), 4097 * 4, hipMemcpyHostToDevice);
@@ -119,15 +125,17 @@ int main() {
                 else if (kind == 4) hipLaunchKernelGGL(burn<4>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 else if (kind == 5) hipLaunchKernelGGL(burn<5>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 else if (kind == 6) hipLaunchKernelGGL(burn<6>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
-                else hipLaunchKernelGGL(burn<7>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 7) hipLaunchKernelGGL(burn<7>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else if (kind == 8) hipLaunchKernelGGL(burn<8>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
+                else hipLaunchKernelGGL(burn<9>, dim3(blocks), dim3(256), 0, 0, dseed, dout, iters, dclk);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep >= 3 && ms < best) best = ms;
                 hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost);
             }
-            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 || kind >= 6 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : kind == 4 ? 2.0 * 16 * 16 * 32 : kind == 5 ? 2.0 * 16 * 16 * 128 : 2.0 * 32 * 32 * 64);
+            const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 /*mfma per iteration*/ * (kind == 0 || kind == 2 || kind == 6 || kind == 7 ? 2.0 * 32 * 32 * 16 : kind == 3 ? 2.0 * 32 * 32 * 32 : kind == 4 ? 2.0 * 16 * 16 * 32 : kind == 5 ? 2.0 * 16 * 16 * 128 : 2.0 * 32 * 32 * 64);
             printf("%s, %s operands: %.3f ms for %d x 16 MFMAs per wave, 2 waves per SIMD on %d CUs: %.0f TFLOP/s; shader clock %.0f MHz\n",
-                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 6 ? "v_mfma_f32_32x32x16_f16 + 1.5 LDS reads per MFMA" : kind == 7 ? "v_mfma_f32_32x32x16_f16 + 1.0 LDS read per MFMA" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : kind == 4 ? "v_mfma_f32_16x16x32_f16" : kind == 5 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
+                   kind == 0 ? "v_mfma_f32_32x32x16_f16" : kind == 6 ? "v_mfma_f32_32x32x16_f16 + 1.5 LDS reads per MFMA" : kind == 7 ? "v_mfma_f32_32x32x16_f16 + 1.0 LDS read per MFMA" : kind == 2 ? "v_mfma_f32_32x32x16_bf16" : kind == 3 ? "v_mfma_i32_32x32x32_i8" : kind == 4 ? "v_mfma_f32_16x16x32_f16" : kind == 5 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)" : kind == 8 ? "v_mfma_scale_f32_32x32x64_f8f6f4 (e2m3)" : kind == 9 ? "v_mfma_scale_f32_32x32x64_f8f6f4 (e2m1)" : "v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)", rnd ? "random" : "zero", best, iters, ncu, flops / best / 1e9,
                    hc[1] ? (double)hc[0] * 100.0 / (double)hc[1] : 0.0);
         }
     return 0;

@@ -215,6 +215,51 @@ def test_c4_large_shard_b32_s1024(dtype, c_generated_weights):
         eng.close()
 
 
+def test_c4_global_batch_256_as_eight_shards_on_one_gpu(c_generated_weights):
+    """BASELINE config c4 at its GLOBAL size on the real engine: gliclass-large, 256 rows of 1024 tokens — the batch the
+    reference's loop walks in chunks (/root/reference/main.c:141-150, src/parallel_processor.c:28-45) and this build partitions over 8 GPUs
+    (bench.py shard_rows).  One GPU plays all eight ranks: shard g = rows shard_rows(256, 8, g), each forwarded on its
+    own, concatenated in rank order — (i) equal to the one-piece forward of all 256 rows (every row is independent end to end: the
+    partition must not be visible), (ii) rows 0 / 100 / 255 against the CPU oracle, (iii) shard independence: a shard forwarded behind a
+    different shard, and with its rows reversed, gives the same probabilities row by row."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import shard_rows
+    from gliclass.c_amd import synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    cfg = CONFIGS["large"]
+    spec = "synthetic:large:42"
+    w = c_generated_weights(spec, cfg)
+    B, S, Cn, G = 256, 1024, 8, 8
+    ids, mask, _ = synth.make_inputs(cfg, B, S, Cn, seed=4321)
+    eng = Engine.from_spec(cfg, spec, dtype="f32")
+    try:
+        eng.set_length_buckets(1)
+        parts = []
+        for g in range(G):
+            lo, hi = shard_rows(B, G, g)
+            assert hi - lo == B // G
+            parts.append(eng.forward(ids[lo:hi], mask[lo:hi]))
+            assert eng.last_mx()
+        stitched = np.concatenate(parts, axis=0)
+        assert stitched.shape == (B, Cn) and np.isfinite(stitched).all()
+        whole = eng.forward(ids, mask)                                     # the same 256 rows in one piece
+        assert eng.last_mx()
+        d = float(np.abs(sig(whole) - sig(stitched)).max())
+        print(f"c4 global batch: 8 stitched shards vs one piece, max |prob diff| = {d:.2e}")
+        assert d <= 1e-5
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, stitched, [0, 100, 255], TOL_MX)
+        print(f"c4 global batch: rows 0 / 100 / 255 vs the oracle: {err:.2e} (asserted {TOL_MX}, bar {BAR})")
+        lo, hi = shard_rows(B, G, 5)
+        again = eng.forward(ids[lo:hi], mask[lo:hi])                       # behind the one-piece forward instead of behind shard 4
+        assert np.abs(sig(again) - sig(parts[5])).max() <= 1e-6
+        rev = eng.forward(ids[lo:hi][::-1].copy(), mask[lo:hi][::-1].copy())
+        assert np.abs(sig(rev[::-1]) - sig(parts[5])).max() <= 1e-5
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_c5_decoder_b16_s2048(dtype, c_generated_weights):
     from gliclass.c_amd import synth

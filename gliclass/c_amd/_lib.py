@@ -73,6 +73,7 @@ def hip():
         L.glc_engine_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.glc_engine_forward_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.glc_engine_sync.argtypes = [C.c_void_p]
+        L.glc_engine_device_forward_valid.argtypes = [C.c_void_p]
         L.glc_device_malloc.restype = C.c_void_p
         L.glc_device_malloc.argtypes = [C.c_void_p, C.c_size_t]
         L.glc_device_free.argtypes = [C.c_void_p, C.c_void_p]

@@ -4,6 +4,7 @@
 # f8 MFMA ops) — summarised into gpurun_out/final_<tag>/ {bench_c3.json, kernel_stats.csv, summary.txt, pmc_sq.txt, traffic.json}, every
 # file stamped with the commit the caller passes.  Copy the directory to profiles/<tag>/ and traffic.json over profiles/traffic.json,
 # then run bench.py once more for the committed line (its roofline.traffic reads profiles/traffic.json).
+# Round 5: also the 16-bit throughput mode's FETCH / WRITE passes (traffic.json's f16 entry carries the same commit) and config c5 (bench line + kernel stats).
 # usage: scripts/final_profile_gpu.sh <tag> <commit>
 set -u
 TAG=${1:-r04}
@@ -41,4 +42,30 @@ for k, cs in sorted(acc.items()):
 PY
 find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
+# (round 5) the opt-in 16-bit throughput mode's FETCH / WRITE passes of the SAME build: the f16 entry of traffic.json (it used to be a round-1 pass)
+mkdir -p "$OUT/f16"
+cd /tmp
+BENCH16="$REPO/bench.py --dtype f16 --steps 3 --warmup 1 --cpu-seqs 0 --no-profile --throughput-dtype none"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/f16/pmc_fetch" -o pmc -- python3 $BENCH16 > "$OUT/f16/pmc_fetch.log" 2>&1; echo "f16 fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/f16/pmc_write" -o pmc -- python3 $BENCH16 > "$OUT/f16/pmc_write.log" 2>&1; echo "f16 write rc=$?"
+cd "$REPO"
+python3 scripts/summarize_prof.py "$OUT/f16" f16 base:64:1024 "$COMMIT" > "$OUT/f16/summary.txt" 2>&1
+python3 - "$OUT" <<'PY'
+import json, os, sys
+out = sys.argv[1]
+a = json.load(open(os.path.join(out, "traffic.json")))
+b = json.load(open(os.path.join(out, "f16", "traffic.json")))
+b["f16"]["source"] = os.path.basename(out.rstrip("/")) + "/f16"
+a.update(b)
+json.dump(a, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print("traffic.json:", {k: (v.get("source"), v.get("commit"), sorted(v.get("kernels", {}))) for k, v in a.items()})
+PY
+rm -rf "$OUT/f16/pmc_fetch" "$OUT/f16/pmc_write"
+# (round 5, review item 7) config c5 (decoder backbone, B = 16, S = 2048) of the same build: bench line + rocprofv3 kernel stats
+python3 bench.py --config c5 --cpu-seqs 0 --throughput-dtype none > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"; echo "c5 bench rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c5" -o trace -- python3 $REPO/bench.py --config c5 --steps 2 --warmup 1 --cpu-seqs 0 --no-profile --throughput-dtype none > "$OUT/trace_c5.log" 2>&1; echo "c5 trace rc=$?"
+cd "$REPO"
+find "$OUT/trace_c5" -name "*kernel_stats.csv" -exec cp {} "$OUT/c5_kernel_stats.csv" \;
+rm -rf "$OUT/trace_c5"
 head -12 "$OUT/summary.txt"; tail -c 400 "$OUT/bench_c3.json"

@@ -30,6 +30,7 @@
 #include "glc_common.h"
 #include "glc_kernels.h"
 #include "glc_layout.h"
+#include "glc_pfrag.h"
 
 namespace {
 
@@ -75,7 +76,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 // time; GLC_ATTN_PV16=1 or variant bit 12, never the default.
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them; the stamps
 // pin the instruction order at each boundary, so the stamped build is slower than the one it describes).
-template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false>
+// FIXQ (round 5, default): a wave keeps ITS PQ block (rel-block g = slot - key tile, g mod NW == wave) in registers while it is image slot
+// 0 .. NW - 1 and writes its p2c block to the slot the block has reached; the block that enters takes the registers in place (glc_pfrag.h:
+// one asm block with tied operands) — 8 KB of position rows per wave every NW-th key tile instead of every tile (row requests 18 -> 12 KB per
+// wave and tile; the L2 -> CU path is the band kernels' busiest resource: DESIGN.md §3g).  Results bit-identical (the same products).
+template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     static_assert(NW == 8 || NW == 4, "workgroup shapes: 8 waves x 1 per CU, 4 waves x 2 per CU");
     constexpr int LROWP = 32 * (NW + 1) + 4;            // floats per p2c image row
@@ -391,7 +396,22 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         }
         const float* c2p_even = c2p_l + c * LROW + rr_base;
         MxFrag pq, pqx;
-        load_rows(PQg, block_x(q0, kt_a), pq);
+        PFrag pqr;                                              // FIXQ: the resident block
+        int eq_n = 0;                                           // FIXQ: table offset (x) of the block that enters at the next key tile but one
+        auto rows_vf = [&](int off) -> unsigned { return (unsigned)((off & ~8191) + ((off & 8191) >> 1) + h * 512); };
+        auto rows_vx = [&](int off) -> unsigned { return (unsigned)(off + 4096 + h * 1024); };
+        if constexpr (FIXQ) {
+            const int offp = block_x(Q0 + 32 * ((wave + kt_a) & (NW - 1)), kt_a);
+            const unsigned vf = rows_vf(offp), vx = rows_vx(offp);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pqr.f[s] = *reinterpret_cast<const f16x8*>(PQg + (size_t)vf + s * 1024);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                pqr.xa[m] = *reinterpret_cast<const glc_i32x4*>(PQg + (size_t)vx + m * 2048);
+                pqr.xb[m] = *reinterpret_cast<const glc_i32x4*>(PQg + (size_t)vx + (m * 2048 + 16));
+            }
+            eq_n = block_x(Q0, kt_a + 1);
+        } else load_rows(PQg, block_x(q0, kt_a), pq);
         if ((kt_a % NW) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
         int2 od_n = block_xy(q0, kt_a + 1);
         int odx_n = block_x(QX, kt_a + 1);
@@ -413,6 +433,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else wg_barrier_all();
             stamp(0);                                           // seg 0: wait for last tile's requests
+            if constexpr (FIXQ) asm volatile("" : "+v"(pqr.f[0]), "+v"(pqr.f[1]), "+v"(pqr.f[2]), "+v"(pqr.f[3]), "+v"(pqr.xa[0]), "+v"(pqr.xb[0]), "+v"(pqr.xa[1]), "+v"(pqr.xb[1]));      // (the block's uses stay behind the wait: its in-place request is not tracked by the compiler)
+            const int eq = eq_n;                                // x offset of block_x(Q0, kt + 1)
+            if constexpr (FIXQ) eq_n = block_x(Q0, kt + 2);
+            const int jm = FIXQ ? ((wave + kt) & (NW - 1)) : wave;      // image slot of this wave's p2c block
             MxFrag pk;
             const int2 od = od_n;
             const int odx = odx_n;
@@ -436,7 +460,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             f32x16 bacc, bacc2;
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
-            mm_hl_lh(pq, kf, bacc);
+            if constexpr (FIXQ) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) f16mm(pqr.f[s], kf.f[s], bacc, s);
+                if constexpr (ABL != 1) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) bacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(pqr.xa[m], pqr.xb[m]), kf.x[m], bacc, 0, 0, 1, SC, 0, SC);
+                }
+            } else mm_hl_lh(pq, kf, bacc);
             if (extra) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) bacc2[i] = 0.f;
@@ -450,12 +481,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             load_rows(PKg, od.y, pk);
             __builtin_amdgcn_sched_barrier(0);
-            load_rows(PQg, od.x, pq);
+            if constexpr (FIXQ) pfrag_load_if(jm == NW - 1 && kt + 1 < kt_b, PQg, rows_vf(eq), rows_vx(eq), pqr);      // the block's last tile as a main slot: the block that enters takes its registers
+            else load_rows(PQg, od.x, pq);
             __builtin_amdgcn_sched_barrier(0);
             stamp(2);                                           // seg 2: row requests (8 waves x 16-24 KB through the CU's vector-memory path)
             wg_barrier_lds();                                   // X: every wave has finished gathering the previous tile's image
             stamp(3);                                           // seg 3: barrier X
-            band_store(img + c * LROWP + 32 * wave, bacc);
+            band_store(img + c * LROWP + 32 * jm, bacc);
             if (extra) band_store(img + c * LROWP + 32 * NW, bacc2);
             wg_barrier_lds();                                   // Y: image complete; tile kt + 1 is in the ring for everyone
             stamp(4);                                           // seg 4: image stores (wait for the p2c MFMA results) + barrier Y
@@ -575,9 +607,11 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     static const bool pv16_env = glc_dev_env("GLC_ATTN_PV16") && atoi(glc_dev_env("GLC_ATTN_PV16")) != 0;
     if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
     if (a.variant & 65536) return go(attn_mx_kernel<NW, 4, false, true>, r7);    // bit 16: timing only, f16 MFMAs in the 16x16x32 shape
+    static std::atomic<unsigned> r8{0};
+    if (a.variant & 131072) return go(attn_mx_kernel<NW, 0, false, true, false>, r8);     // bit 17: PQ rows requested every key tile (round 4's form; A/B)
     if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
 #else
-    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
+    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536 | 131072))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
 #endif
     return go(attn_mx_kernel<NW, 0, false, true>, r0);
 }

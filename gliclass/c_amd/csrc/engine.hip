@@ -1690,10 +1690,10 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
     which %= 1000;
     const int which_in = which;
     if (which >= 100) which %= 100;
-    const bool w128b = which == 14;                   // ... one wave per SIMD, 128 x 128 wave tiles
+    if (which == 14) { set_err("gemm_bench: the one-wave-per-SIMD 128 x 128 wave tile (which = 14) was deleted in round 5 (DESIGN.md section 9)"); return -1.f; }
     const bool z16b = which == 13;                    // the GX kernel with the 16 x 16 MFMA shapes
     const bool gyb = which == 11 || which == 12;      // the same kernel on GY rows (e2m3 parts with block scales); 12: plus one stamped launch
-    const bool mxb = which == 9 || which == 10 || gyb || z16b || w128b;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
+    const bool mxb = which == 9 || which == 10 || gyb || z16b;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
     const bool gsb = which == 6 || which == 8 || mxb;
     const int mx_ws = glc_gx_weight_exponent(0.5f);
     if (!e || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (e->dtype == GLC_F32 && !gsb) || epi < EPI_BIAS || epi > EPI_RESID) { set_err("gemm_bench: bad args"); return -1.f; }
@@ -1727,7 +1727,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
         if (mxb && which_in >= 100) g.prio_mode = which_in / 100 - 1;      // which = 100 (1 + prio) + 9 | 10
         g.epi_abl = mxb ? epi_abl : 0;
         g.gy = gyb ? 1 : 0;
-        g.z16 = z16b ? 1 : 0; g.w128 = w128b ? 1 : 0;
+        g.z16 = z16b ? 1 : 0;
         const char* m = nullptr;
         auto launch = [&]() -> const char* { return mxb ? glc_launch_gemm256x(e->stream, epi, g) : gsb ? glc_launch_gemm256s_gs(e->stream, epi, g) : which == 1 ? glc_launch_gemm(e->stream, e->dtype, epi, g) : (which == 5 || which == 7) ? glc_launch_gemm256s(e->stream, e->dtype, epi, g) : glc_launch_gemm_auto(e->stream, e->dtype, epi, g); };
         for (int i = 0; i < 2 && !m; ++i) m = launch();
@@ -1777,8 +1777,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
  * out[0] = max |mx - gs|, out[1] = max |gs|, out[2] = rms(mx - gs), out[3] = rms(gs) over the decoded outputs (mode 2: + the ln_part
  * sums in out[4] = max |diff|).  Returns 0 or < 0. */
 int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, int mode, double* out) {
-    const bool w128 = mode >= 30;        // mode + 30: one wave per SIMD, 128 x 128 wave tiles (GemmArgs::w128)
-    if (w128) mode -= 30;
+    if (mode >= 30) { set_err("gemm_mx_check: mode + 30 (the one-wave-per-SIMD 128 x 128 wave tile) was deleted in round 5 (DESIGN.md section 9)"); return -1; }
     const bool z16 = mode >= 20;         // mode + 20: the MX leg's main loop on the 16 x 16 MFMA shapes (GemmArgs::z16)
     if (z16) mode -= 20;
     const bool gy = mode >= 10;          // mode + 10: the MX leg on GY rows (e2m3 parts with block scales) instead of GX rows
@@ -1845,7 +1844,7 @@ int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, flo
         if (mode == 4) { g.Qh = C1; g.Kh = C1 + third; g.Vt = C1 + 2 * third; }
         const bool rows_out = mode == 1 || mode == 2;
         if (gy) { g.gy = 1; g.A = Ay; g.W = Wy; g.resid = Ry; if (rows_out) g.C = Cy; }
-        g.z16 = z16 ? 1 : 0; g.w128 = w128 ? 1 : 0;
+        g.z16 = z16 ? 1 : 0;
         if (!m) m = glc_launch_gemm256x(e->stream, epi, g);
         if (gy && rows_out && !m) m = glc_launch_gy_to_f32(e->stream, Cy, C1, M, N);        // (the GY output rows decoded on the device)
         if (m) { set_err(m); break; }

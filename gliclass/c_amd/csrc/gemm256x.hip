@@ -610,7 +610,7 @@ const char* glc_launch_gemm256x_dev(hipStream_t st, int epi, const GemmArgs& a);
 
 const char* glc_launch_gemm256x(hipStream_t st, int epi, const GemmArgs& a_in) {
     GemmArgs a = a_in;
-    if (a.gy || a.z16 || a.w128 || a.stamps || a.epi_abl || a.prio_mode >= 4) {
+    if (a.gy || a.z16 || a.stamps || a.epi_abl || a.prio_mode >= 4) {
 #ifdef GLC_DEVELOPER
         return glc_launch_gemm256x_dev(st, epi, a_in);
 #else

@@ -71,7 +71,6 @@ struct GemmArgs {
     int qkv_mxt = 0;                        // gemm256x, EPI_QKV: write Q / K / V^T as MX tiles (glc_layout.h) for attention_mx.hip instead of split-f16 units
     int mx_ws = 0;                          // gemm256x: exponent of W's fp8 parts (GX rows written with glc_launch_to_gx(.., mx_ws))
     unsigned* gx_sat = nullptr;             // gemm256x: fp8 range guard counter (filled by the launcher from glc_gx_sat_ptr())
-    int w128 = 0;                           // gemm256x (developer builds): four waves, one per SIMD, 128 x 128 per wave on the 16 x 16 MFMA shapes
     int z16 = 0;                            // gemm256x: the main loop on v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4 (same GX images; K % 64 == 0)
     int gy = 0;                             // gemm256x: A, W, resid and C (where they are operand images) are GY rows — e2m3 parts with block scales (glc_common.h) — not GX rows
     int act_sc = 0;                         // gemm256x: exponent of the ACTIVATION GX rows it reads (A, resid) and writes (C); 0 unless the engine lowered it (engine.hip act_sc)

@@ -1,4 +1,4 @@
-"""Developer tool (GPU): the bucket-space MX attention (attention_mx2.hip) against the band kernel (attention_mx.hip) on the SAME MX tiles —
+"""Developer tool (GPU): the bucket-space MX attention (attention_mx2.hip) against the band kernel (attention_mx.hip) on the SAME MX tiles —  [needs a developer build: make -C gliclass/c_amd DEV=1 (csrc/dev/attention_mx2.hip)]
 context rows compared element by element (both kernels run the same products; differences are accumulation order), then interleaved timing.
 usage: attn_mx2_check.py [stamps 0/1]   env: GLC_B, GLC_S, GLC_CONFIG, GLC_RAGGED"""
 import ctypes, os, sys

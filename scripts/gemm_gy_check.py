@@ -1,4 +1,4 @@
-"""Developer tool (GPU): the MX cross-term GEMM on GY rows (e2m3 parts with per-block scales, glc_common.h) — numerics of every epilogue
+"""Developer tool (GPU): the MX cross-term GEMM on GY rows (e2m3 parts with per-block scales, glc_common.h) — numerics of every epilogue  [needs a developer build: make -C gliclass/c_amd DEV=1 (GY images live in csrc/dev/gemm256x_dev.hip)]
 against the split-f16 GEMM, then timing against the same kernel on GX rows (e4m3 parts)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

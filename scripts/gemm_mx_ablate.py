@@ -1,4 +1,4 @@
-"""Developer tool (GPU, make DEV=1): timing-only ablations of the MX GEMM main loop (prio_mode 4 / 5 / 6: no fragment reads / no DMA / no
+"""Developer tool (GPU, make DEV=1): timing-only ablations of the MX GEMM main loop (prio_mode 4 / 5 / 6: no fragment reads / no DMA / no  [needs a developer build: make -C gliclass/c_amd DEV=1 (timing-only builds live in csrc/dev/gemm256x_dev.hip)]
 MFMAs; 7: the traffic and MFMA format fp6 cross terms would have — 7/8 of the DMA, 24-byte scaled fragments, e2m3 MFMAs)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""Developer tool (GPU): phase-by-phase cycle account of the 256-tile GEMM main loop (stamped build, glc_debug_gemm_bench which = 7 / 8)."""
+"""Developer tool (GPU): phase-by-phase cycle account of the 256-tile GEMM main loop (stamped build, glc_debug_gemm_bench which = 7 / 8)."""  [needs a developer build: make -C gliclass/c_amd DEV=1 (stamped builds)]
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""Developer tool (GPU): the MX cross-term GEMM with its main loop on the 16 x 16 MFMA shapes (v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4,
+"""Developer tool (GPU): the MX cross-term GEMM with its main loop on the 16 x 16 MFMA shapes (v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4,  [needs a developer build: make -C gliclass/c_amd DEV=1 (the 16 x 16 shapes live in csrc/dev/gemm256x_dev.hip)]
 GemmArgs::z16) — numerics of every epilogue against the split-f16 GEMM, then timing against the 32 x 32 loop on the same GX images."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -80,7 +80,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 // 0 .. NW - 1 and writes its p2c block to the slot the block has reached; the block that enters takes the registers in place (glc_pfrag.h:
 // one asm block with tied operands) — 8 KB of position rows per wave every NW-th key tile instead of every tile (row requests 18 -> 12 KB per
 // wave and tile; the L2 -> CU path is the band kernels' busiest resource: DESIGN.md §3g).  Results bit-identical (the same products).
-template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true>
+template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true, bool XROT = FIXQ>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     static_assert(NW == 8 || NW == 4, "workgroup shapes: 8 waves x 1 per CU, 4 waves x 2 per CU");
     constexpr int LROWP = 32 * (NW + 1) + 4;            // floats per p2c image row
@@ -412,7 +412,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             }
             eq_n = block_x(Q0, kt_a + 1);
         } else load_rows(PQg, block_x(q0, kt_a), pq);
-        if ((kt_a % NW) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
+        // the wave that computes the block nobody owns at key tile t: t mod NW in round 4's form; with resident blocks the wave NW - 2 - t (mod NW) —
+        // never the wave that requests its entering block during the tile before (that one already issues 16 row requests, with these 24)
+        auto extra_wave = [&](int t) -> int { return XROT ? ((NW - 2 - t) & (NW - 1)) : (t % NW); };
+        if (extra_wave(kt_a) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
         int2 od_n = block_xy(q0, kt_a + 1);
         int odx_n = block_x(QX, kt_a + 1);
         unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0, tlast = 0;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             }
         };
         auto band_tile = [&](const int kt, const int xr) __attribute__((always_inline)) {
-            const bool extra = (kt % NW) == wave;               // wave-uniform: this wave also computes the block nobody owns
+            const bool extra = extra_wave(kt) == wave;          // wave-uniform: this wave also computes the block nobody owns
             stamp(-1);
             // everything requested during tile kt - 1 has arrived (rows, offsets, my DMA pieces); NW = 4: barrier Z — key tile kt is in LDS for everyone
             if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             mm_lh_hl(kf, qf, sacc);
             __builtin_amdgcn_sched_barrier(0);
             stamp(1);                                           // seg 1: K fragments, c2p gather, p2c + S^T MFMA issue
-            if (((kt + 1) % NW) == wave) load_rows(PQg, odx, pqx);
+            if (extra_wave(kt + 1) == wave) load_rows(PQg, odx, pqx);
             __builtin_amdgcn_sched_barrier(0);
             load_rows(PKg, od.y, pk);
             __builtin_amdgcn_sched_barrier(0);
@@ -608,10 +611,12 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     if ((a.variant & 4096) || pv16_env) return go(attn_mx_kernel<NW, 3>, r5);
     if (a.variant & 65536) return go(attn_mx_kernel<NW, 4, false, true>, r7);    // bit 16: timing only, f16 MFMAs in the 16x16x32 shape
     static std::atomic<unsigned> r8{0};
+    static std::atomic<unsigned> r9{0};
+    if (a.variant & 262144) return go(attn_mx_kernel<NW, 0, false, true, true, false>, r9);     // bit 18: resident blocks, the extra block on wave t mod NW (A/B)
     if (a.variant & 131072) return go(attn_mx_kernel<NW, 0, false, true, false>, r8);     // bit 17: PQ rows requested every key tile (round 4's form; A/B)
     if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
 #else
-    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536 | 131072))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
+    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536 | 131072 | 262144))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
 #endif
     return go(attn_mx_kernel<NW, 0, false, true>, r0);
 }

@@ -35,7 +35,7 @@ while time.time() - t0 < budget:
         e.set_mx(False); x = e.forward(ids, mask); e.set_mx(True)
         d = float(np.abs(sig(a) - sig(x)).max())
         if d > worst: worst = d; print(f"new worst MX vs split {d:.3e} at B={B} S={S} C={Cn} ragged={int(mask.min() == 0)} buckets={e_b}", flush=True)
-        if d > 4.5e-4: print(f"TOLERANCE B={B} S={S} C={Cn}: MX vs split {d:.3e}", flush=True)
+        if d > 5e-4: print(f"TOLERANCE B={B} S={S} C={Cn}: MX vs split {d:.3e}", flush=True)
     if rounds % 20 == 0: print(f"{time.time() - t0:6.0f} s: {rounds} shapes ({mx_rounds} on the MX pipeline), {mism} mismatches, worst MX vs split {worst:.2e}", flush=True)
 print(f"done: {rounds} shapes ({mx_rounds} MX), {mism} run-to-run mismatches, worst MX vs split {worst:.2e}")
 e.close()

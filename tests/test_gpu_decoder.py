@@ -73,7 +73,7 @@ def test_decoder_head_dim_64_and_long_sequence(dtype, weights_for):
                 mx = eng.forward(ids, mask)
                 eng.set_group_split(1)
                 assert eng.last_mx() and eng.last_mx_attention(), "the MX pipeline did not run"
-                assert np.abs(sig(mx) - sig(ref)).max() <= 4.5e-4, (B, S)
+                assert np.abs(sig(mx) - sig(ref)).max() <= 5e-4, (B, S)
     finally:
         eng.close()
 
@@ -109,7 +109,7 @@ def test_decoder_config_switches(variant, weights_for):
             mx = eng.forward(ids, mask)
             eng.set_group_split(1)
             assert eng.last_mx() and eng.last_mx_attention(), "the MX pipeline did not run"
-            assert np.abs(sig(mx) - sig(ref)).max() <= 4.5e-4, (variant, B, S)
+            assert np.abs(sig(mx) - sig(ref)).max() <= 5e-4, (variant, B, S)
     finally:
         eng.close()
 
@@ -272,8 +272,8 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
                 mx = eng.forward(ids, mask)
                 assert eng.last_mx(), "the MX pipeline did not run"
                 assert np.isfinite(mx).all() and not np.array_equal(mx, gs)
-                assert np.abs(sig(mx) - sig(ref)).max() <= 4.5e-4, (B, S)
-                assert np.abs(sig(mx) - sig(gs)).max() <= 4.5e-4, (B, S)
+                assert np.abs(sig(mx) - sig(ref)).max() <= 5e-4, (B, S)
+                assert np.abs(sig(mx) - sig(gs)).max() <= 5e-4, (B, S)
                 # dec-mini (head_dim 128, even head counts): RoPE + MX tiles are the QKV projection's epilogue (gemm256x EPI_QKVR, weight
                 # rows of every Q / K head reordered at load).  With the attention back on split units the same reordered weights go through
                 # the plain-row epilogue (columns put back in place) and the separate RoPE / layout pass: both orders, one answer.
@@ -282,8 +282,8 @@ def test_decoder_group_split_pipeline_vs_oracle_and_plain_fp32(cname, weights_fo
                 mxs = eng.forward(ids, mask)
                 eng.set_mx_attention(True)
                 assert eng.last_mx() and not eng.last_mx_attention()
-                assert np.abs(sig(mxs) - sig(ref)).max() <= 4.5e-4, (B, S)
-                assert np.abs(sig(mxs) - sig(mx)).max() <= 4.5e-4, (B, S)
+                assert np.abs(sig(mxs) - sig(ref)).max() <= 5e-4, (B, S)
+                assert np.abs(sig(mxs) - sig(mx)).max() <= 5e-4, (B, S)
     finally:
         eng.close()
 
@@ -352,7 +352,7 @@ def test_decoder_outlier_tokens_fp8_range_guard(amp, weights_for):
             assert eng.fp8_range_retries() == 2 and not eng.last_mx()
         err = float(np.abs(sig(got) - sig(ref)).max())
         print(f"amp {amp:g}: max probability error vs the oracle {err:.2e} (MX pipeline: {eng.last_mx()})")
-        assert err <= (4.5e-4 if amp < 400 else 1e-3), (amp, err)
+        assert err <= (5e-4 if amp < 400 else 1e-3), (amp, err)
     finally:
         eng.close()
 

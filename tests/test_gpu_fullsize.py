@@ -23,9 +23,9 @@ pytestmark = pytest.mark.gpu
 
 BAR = 1e-3
 TOL_DEFAULT_MODE = 1e-4      # split-f16 projections (GLICLASS_MX=0, and every forward too small for the 256-tile pipeline)
-TOL_MX = 4.5e-4          # MX arithmetic of large forwards.  Observed worst case 2.2e-4 (soak: 5166 shapes) / 1.8e-4 (profiles/r05/mx_margin_probe.txt: short rows, S = 256-320 —
-                        # ~1.0e-4 from the GX-row projections + ~0.8e-4 from the MX-tile attention); asserted at >= 2x that (round 4 asserted 3e-4 = 1.36x: a flake
-                        # waiting for a seed) and still 2.2x inside the bar (1e-3, /root/reference/ONNX_CONVERTING/test_onnx.py:30)
+TOL_MX = 5e-4          # MX arithmetic of large forwards.  Observed worst case 2.4e-4 (soaks of round 5: 7273 + 5051 shapes on the MX pipeline, profiles/r05/soak_*.txt) / 1.8e-4 (profiles/r05/mx_margin_probe.txt: short rows, S = 256-320 —
+                        # ~1.0e-4 from the GX-row projections + ~0.8e-4 from the MX-tile attention); asserted at half the bar = 2.1x that (round 4 asserted 3e-4 = 1.36x: a flake
+                        # waiting for a seed) against the bar (1e-3, /root/reference/ONNX_CONVERTING/test_onnx.py:30)
 ENVELOPE = {"f16": 1e-2, "bf16": 6e-2}
 
 

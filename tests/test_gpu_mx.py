@@ -58,7 +58,7 @@ def test_mx_pipeline_odd_batch_shapes():
             eng.set_mx(True)
             assert not np.array_equal(got, ref)
             d = float(np.abs(sig(got) - sig(ref)).max())
-            assert d <= 4.5e-4, (B, S, Cn, d)                    # (TOL_MX of test_gpu_parity.py: 2x the observed worst case)
+            assert d <= 5e-4, (B, S, Cn, d)                    # (TOL_MX of test_gpu_parity.py: 2x the observed worst case)
         assert eng.L.glc_debug_mx_weight_bytes(eng.h) > 11 * 4 * 7077888       # (base: 12 layers x ~7.1 M projection weights x 4 bytes, minus the pruned layer's folded copies)
     finally:
         eng.close()
@@ -98,7 +98,7 @@ def test_mx2_bucket_space_attention_vs_band_kernel_and_oracle():
                 b = B // 2
                 n = int(mask[b].sum())
                 ref = oracle_c.forward(cfg, w, ids[b:b + 1, :n], mask[b:b + 1, :n])
-                assert np.abs(sig(got[b:b + 1, :ref.shape[1]]) - sig(ref)).max() <= 4.5e-4, (B, S)
+                assert np.abs(sig(got[b:b + 1, :ref.shape[1]]) - sig(ref)).max() <= 5e-4, (B, S)
     finally:
         eng.close()
 
@@ -237,7 +237,7 @@ def test_mxs_role_split_attention_vs_band_kernel_and_oracle():
                 b = B // 2
                 n = int(mask[b].sum())
                 ref = oracle_c.forward(cfg, w, ids[b:b + 1, :n], mask[b:b + 1, :n])
-                assert np.abs(sig(got[b:b + 1, :ref.shape[1]]) - sig(ref)).max() <= 4.5e-4, (B, S)
+                assert np.abs(sig(got[b:b + 1, :ref.shape[1]]) - sig(ref)).max() <= 5e-4, (B, S)
         eng.set_mxs(False)
     finally:
         eng.close()
@@ -306,6 +306,6 @@ def test_fp8_range_guard_encoder_outlier_channel(gain):
             span = max(span, float(np.abs(ref).max()))
         print(f"gain {gain:g}: max probability error vs the oracle {worst:.2e}, largest |logit| {span:.2f} (MX pipeline: {eng.last_mx()})")
         assert 0.05 < span < 30, "the logits should sit in the sigmoid's range for the comparison to mean something"
-        assert worst <= (4.5e-4 if gain < 16 else 1e-3), (gain, worst)         # (bar for the outlier models: the reference's own 1e-3)
+        assert worst <= (5e-4 if gain < 16 else 1e-3), (gain, worst)         # (bar for the outlier models: the reference's own 1e-3)
     finally:
         eng.close()

@@ -29,9 +29,9 @@ def test_product_library_ships_only_shipping_kernel_instantiations():
     # rejected experiments live in csrc/dev/ and are not linked
     for gone in ("attn_mx2_kernel", "gemm256w_kernel", "to_gy_kernel", "gy_to_f32_kernel"):
         assert gone not in text, gone
-    # band kernel on MX tiles: <NW, ABL = 0, DIAG = false, RECOMP = true, FIXQ = true> only
+    # band kernel on MX tiles: <NW, ABL = 0, DIAG = false, RECOMP = true, FIXQ = true, XROT = true> only
     mx = [k for k in ks if "attn_mx_kernel<" in k]
-    assert mx and all(re.search(r"attn_mx_kernel<[48], 0, false, true, true>", k) for k in mx), mx
+    assert mx and all(re.search(r"attn_mx_kernel<[48], 0, false, true, true, true>", k) for k in mx), mx
     # role-split kernel: <DIAG = false, XPRIO = 0> only
     mxs = [k for k in ks if "attn_mxs_kernel<" in k]
     assert mxs and all("attn_mxs_kernel<false, 0>" in k for k in mxs), mxs

@@ -1470,7 +1470,13 @@ int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_
 int glc_debug_activation_exponent(const glc_engine* e) { return e ? e->act_sc : 1; }
 long long glc_debug_mx_weight_bytes(const glc_engine* e) { return e ? (long long)e->mx_bytes : -1; }
 int glc_debug_set_mxs(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mxs = on != 0; return 0; }
-int glc_debug_set_mx2(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mx2 = on != 0; return 0; }
+int glc_debug_set_mx2(glc_engine* e, int on) {
+    if (!e) return -1;
+#ifndef GLC_DEVELOPER
+    if (on) { set_err("set_mx2: the bucket-space attention kernel exists in developer builds only (make DEV=1)"); return -1; }
+#endif
+    std::lock_guard<std::mutex> lk(e->mu); e->mx2 = on != 0; return 0;
+}
 
 int glc_engine_set_length_buckets(glc_engine* e, int max_groups) {
     if (!e || max_groups < 1 || max_groups > 64) { set_err("set_length_buckets: 1..64 groups"); return -1; }

@@ -145,12 +145,13 @@ class Engine:
         return int(self.L.glc_debug_activation_exponent(self.h))
 
     def set_mxs(self, on):
-        """MX attention on the role-split kernel (attention_mxs.hip) or on the band kernel (attention_mx.hip); same results bit for bit"""
+        """MX attention on the role-split kernel (attention_mxs.hip) or on the band kernel (attention_mx.hip); same results to rounding (<= 1e-4 of a row's scale)"""
         self.L.glc_debug_set_mxs(self.h, int(bool(on)))
 
     def set_mx2(self, on):
-        """MX attention on the bucket-space kernel (attention_mx2.hip) or on the band kernel (attention_mx.hip)"""
-        self.L.glc_debug_set_mx2(self.h, int(bool(on)))
+        """developer builds (make DEV=1): MX attention on the bucket-space kernel (csrc/dev/attention_mx2.hip) or on the band kernel; the product library refuses on=True"""
+        if self.L.glc_debug_set_mx2(self.h, int(bool(on))) != 0:
+            raise RuntimeError(self.L.glc_last_error().decode())
 
     def range_retries(self):
         """host-buffer forwards repeated with the norms unfused because the folded forward came out non-finite"""

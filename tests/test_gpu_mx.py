@@ -201,6 +201,8 @@ def test_product_library_has_no_path_to_timing_only_or_stamped_kernels():
         out = (C.c_double * 8)()
         for mode in (10, 20, 30):                                                    # GY images, 16 x 16 shapes, (deleted) 128 x 128 wave tile
             assert L.glc_debug_gemm_mx_check(eng.h, 512, 768, 768, 1.0, 0.02, mode, out) != 0, mode
+        with pytest.raises(RuntimeError, match="developer builds only"):            # no silent no-op either: the switch itself refuses
+            eng.set_mx2(True)
     finally:
         eng.close()
 

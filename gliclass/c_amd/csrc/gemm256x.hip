@@ -37,8 +37,16 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem256x[];
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
+#ifndef GLC_GX_A_AUX
+#define GLC_GX_A_AUX 0
+#endif
+#ifndef GLC_GX_W_AUX
+#define GLC_GX_W_AUX 0
+#endif
+// AUX: the cache-policy bits of the request (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g, (void __attribute__((address_space(3)))*)l, 16, 0, AUX);
 }
 
 // XCD-aware tile order (gemm256s.hip): this workgroup's (M-tile, N-tile) of a launch over ntn N-tiles
@@ -94,9 +102,9 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         unsigned char* sw = smem256x + ((2 * grp + 1) & (NSLOT - 1)) * STAGE + (wave * 32) * LINE;
         const size_t o = (size_t)grp * LINE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(fa[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sa + i * 8 * LINE);
+        for (int i = 0; i < 4; ++i) glds16<GLC_GX_A_AUX>(fa[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sa + i * 8 * LINE);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(fw[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sw + i * 8 * LINE);
+        for (int i = 0; i < 4; ++i) glds16<GLC_GX_W_AUX>(fw[i & 1] + (size_t)(i >> 1) * 16 * rsb + o, sw + i * 8 * LINE);
     };
 
     f32x16 acc[4][2];
@@ -524,6 +532,10 @@ template <int EPI, bool VMODE> const char* launch_x(hipStream_t st, const GemmAr
     static const int prio_env = glc_dev_env("GLC_GEMM_PRIO") ? atoi(glc_dev_env("GLC_GEMM_PRIO")) : 1;      // developer A/B switch
     b.prio_mode = a.prio_mode >= 0 ? a.prio_mode : prio_env;
     if (ntn >= 8 && (a.Mpad / TM) % 8 == 0) b.n_group = ntn % 4 == 0 ? 4 : (ntn % 3 == 0 ? 3 : 0);      // wide N: as gemm256s.hip
+#ifdef GLC_GX_NB
+    { constexpr int nbv = (GLC_GX_NB) > 0 ? (GLC_GX_NB) : 1;          // build-time A/B of the tile order (scripts/gemm_cache_policy_ab.sh; profiles/r05/gemm_cache_policy.txt)
+      if ((a.Mpad / TM) % 8 == 0) b.n_group = (GLC_GX_NB) > 0 && ntn % nbv == 0 ? nbv : 0; }
+#endif
     hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE>), dim3(grid), dim3(512), lds_bytes, st, b, n_tile0, ntn);
     return nullptr;
 }

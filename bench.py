@@ -378,6 +378,8 @@ def main():
         if "--batch" not in given: args.batch = ab
         if "--seq" not in given: args.seq = asq
         if args.scaling is None: args.scaling = asc
+        # the CPU legs are a BOUNDED sample (about 10-30 s of CPU work): the larger configs cost ~10 s per sequence on the oracle
+        if "--cpu-seqs" not in given and cname in ("large", "qwen-1.5b"): args.cpu_seqs, args.cpu_seqs_8 = 2, 1
     scaling_defaulted = args.scaling is None
     if args.scaling is None:
         args.scaling = "weak"
@@ -530,6 +532,7 @@ def main():
             cpu = None
             ref_logits = rids = rmask = None
             if args.cpu_seqs > 0 and world == 1:
+                print(f"bench: CPU baseline leg ({min(args.cpu_seqs, B)} + {args.cpu_seqs_8} sequences on the oracle) ...", file=sys.stderr, flush=True)
                 cpu, ref_logits, rids, rmask = cpu_baseline(cfg, W.tensors, S, Cn, min(args.cpu_seqs, B), args.cpu_seqs_8)
                 # parity check of the timed configuration itself: same seed => the oracle's rows are the first rows of the timed batch
                 n = rids.shape[0]

@@ -1918,7 +1918,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         set_err("attn_bench: needs a DeBERTa engine (16-bit, or fp32 with split-f16 attention) and a previous forward"); return -1.f;
     }
 #ifndef GLC_DEVELOPER
-    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 65536 | 131072 | 262144))) {
+    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288))) {
         set_err("attn_bench: stamped builds, timing-only builds (wrong results) and the bucket-space kernel exist in developer builds only (make DEV=1)"); return -1.f;
     }
 #endif
@@ -1940,7 +1940,8 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const bool mxk2 = mxk && (variant & 8192) != 0;           // bit 13: the bucket-space MX kernel (attention_mx2.hip)
     if (mxk2 && !(a.idx16 && a.tinfo)) { set_err("attn_bench: no mx2 tables for this length"); return -1.f; }
     const bool mxs = mxk && (variant & 32768) != 0;          // bit 15: the role-split MX kernel (attention_mxs.hip)
-    auto launch = [&]() -> const char* { return mxs ? glc_launch_attention_mxs(st, a) : mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
+    const bool mxd = mxk && (variant & 524288) != 0;         // bit 19: two query tiles per wave, one wave per SIMD (csrc/dev/attention_mxd.hip; developer builds)
+    auto launch = [&]() -> const char* { return mxd ? glc_launch_attention_mxd(st, a) : mxs ? glc_launch_attention_mxs(st, a) : mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
     for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);
     for (int i = 0; i < iters; ++i) launch();
@@ -1989,7 +1990,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
             (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
             AttnArgs as = a; as.stamps = dbuf;
-            const char* m = mxs ? glc_launch_attention_mxs(st, as) : mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
+            const char* m = mxd ? glc_launch_attention_mxd(st, as) : mxs ? glc_launch_attention_mxs(st, as) : mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
             (void)hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(ns);
             if (!m && mxs && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2015,6 +2016,10 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
                     fprintf(stderr, "[attn_mx2 stamps] per generic tile per wave (s_memtime ticks), %.0f tiles: K fragments + c2p store / gather + p2c / S issue %.0f | request wait + ring barrier %.0f | "
                                     "DMA + row requests %.0f | image stores + gathers %.0f | softmax + P.V %.0f | c2p issue %.0f | total %.0f | s_memtime clock %.0f MHz\n",
                             nt, (s[0] + s[1]) / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, s[6] / nt, tot / nt, s[8] / (64 * 8) / 10.0);
+                else if (mxd)
+                    fprintf(stderr, "[attn_mxd stamps] per band step (two query tiles) per wave (s_memtime ticks), %.0f steps: DMA + row requests %.0f | gathers, bias, maxima %.0f | barrier X' %.0f | "
+                                    "M first half + softmax A %.0f | M second half + P.V A + softmax B %.0f | P.V B, c2p, ring stores %.0f | requests landed + barrier Y' %.0f | total %.0f\n",
+                            nt, s[0] / nt, s[1] / nt, s[2] / nt, s[3] / nt, s[4] / nt, s[5] / nt, s[6] / nt, tot / nt);
                 else
                 fprintf(stderr, "[attn_mx stamps] per band tile per wave (s_memtime ticks), %.0f tiles: request wait %.0f | K + c2p gather + p2c/S issue %.0f | row requests %.0f | "
                                 "barrier X %.0f | image stores + barrier Y %.0f | DMA + image gather %.0f | c2p issue + softmax + P.V %.0f | c2p store %.0f | total %.0f | s_memtime clock %.0f MHz\n",

@@ -216,9 +216,11 @@ const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a);
 // structure the kernel needs (the caller keeps glc_launch_attention_mx).
 #include <vector>
 #ifdef GLC_DEVELOPER
+const char* glc_launch_attention_mxd(hipStream_t st, const AttnArgs& a);      // csrc/dev/attention_mxd.hip: two query tiles per wave, one wave per SIMD (round 5)
 const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a);
 bool glc_mx2_build_tables(int Sp, int P, const int32_t* dtab, std::vector<unsigned char>& idx16, std::vector<int4>& tinfo);
 #else
+inline const char* glc_launch_attention_mxd(hipStream_t, const AttnArgs&) { return "attention(mxd): the two-tiles-per-wave kernel exists in developer builds only (make DEV=1)"; }
 inline const char* glc_launch_attention_mx2(hipStream_t, const AttnArgs&) { return "attention(mx2): the bucket-space kernel exists in developer builds only (make DEV=1)"; }
 inline bool glc_mx2_build_tables(int, int, const int32_t*, std::vector<unsigned char>&, std::vector<int4>&) { return false; }
 #endif

@@ -194,7 +194,7 @@ def test_product_library_has_no_path_to_timing_only_or_stamped_kernels():
         cs = (C.c_double * 2)()
         assert L.glc_debug_attn_bench(eng.h, 1, 128, 0, cs) > 0                      # the shipping band kernel
         assert L.glc_debug_attn_bench(eng.h, 1, 128 | 32768, 0, cs) > 0              # the shipping role-split kernel
-        for bits in (256, 512, 4096, 8192, 16384, 65536):                           # ablations, PV16, bucket-space kernel, spilled build, 16x16 timing build
+        for bits in (256, 512, 4096, 8192, 16384, 65536, 524288):                   # ablations, PV16, bucket-space kernel, spilled build, 16x16 timing build, two-tiles-per-wave kernel
             assert L.glc_debug_attn_bench(eng.h, 1, 128 | bits, 0, cs) < 0, bits
             assert b"developer builds only" in L.glc_last_error(), bits
         assert L.glc_debug_attn_bench(eng.h, 1, 128, 1, cs) < 0                      # stamps
@@ -203,6 +203,42 @@ def test_product_library_has_no_path_to_timing_only_or_stamped_kernels():
             assert L.glc_debug_gemm_mx_check(eng.h, 512, 768, 768, 1.0, 0.02, mode, out) != 0, mode
         with pytest.raises(RuntimeError, match="developer builds only"):            # no silent no-op either: the switch itself refuses
             eng.set_mx2(True)
+    finally:
+        eng.close()
+
+
+def test_mxd_two_tiles_per_wave_attention_vs_band_kernel():
+    """Round 5, developer kernel (csrc/dev/attention_mxd.hip: two query tiles per wave, one wave per SIMD, software-pipelined; make DEV=1 — skipped on
+    the product library): context rows against the band kernel on the SAME MX tiles of a forward, through the attention microbenchmark.  Same products
+    except the order in which the c2p band joins the scores and one shared product on saturated tiles: rows of magnitude ~5 must agree to two units of
+    the GX output format (2.5e-4; measured 1.2e-4).  Shapes: both saturated ends (S >= 1000), Sp % 256 != 0 (inactive waves), a single tile pair, ragged."""
+    from gliclass.c_amd import _lib, synth
+    from gliclass.c_amd.config import CONFIGS
+    from gliclass.c_amd.engine import Engine
+    L = _lib.hip()
+    if not L.glc_debug_is_developer_build():
+        pytest.skip("attention_mxd is compiled into developer builds only (make DEV=1)")
+    cfg = CONFIGS["base"]
+    eng = Engine.from_spec(cfg, "synthetic:base:42", dtype="f32")
+    try:
+        eng.set_length_buckets(1); eng.set_group_split(2)
+        for (B, S, ragged) in ((16, 1024, False), (5, 640, True), (3, 192, True), (2, 64, False), (2, 1536, True)):
+            ids, mask, _ = synth.make_inputs(cfg, B, S, 8, seed=3, ragged=ragged)
+            L.glc_debug_set_stop(eng.h, 1); eng.forward(ids, mask)
+            assert eng.last_mx_attention(), (B, S)
+            Sp = (S + 63) // 64 * 64
+            rows = B * Sp
+            out = {}
+            for v in (128, 128 | 524288):
+                cs = (C.c_double * 2)()
+                assert L.glc_debug_attn_bench(eng.h, 1, v, 0, cs) > 0, L.glc_last_error()
+                buf = np.zeros((rows, cfg.hidden), np.float32)
+                L.glc_debug_read_workspace(eng.h, 2, rows, buf.ctypes.data_as(C.c_void_p))
+                out[v] = buf.reshape(B, Sp, cfg.hidden)
+            valid = np.zeros((B, Sp), bool); valid[:, :S] = mask.astype(bool)
+            d = float(np.abs(out[128] - out[128 | 524288])[valid].max())
+            assert np.isfinite(out[128 | 524288][valid]).all() and d <= 2.5e-4, (B, S, d)
+        L.glc_debug_set_stop(eng.h, -1)
     finally:
         eng.close()
 

@@ -25,8 +25,9 @@
 // AMDGPURewriteAGPRCopyMFMA — keep the pressure below the limit.)
 // What the measurements say (profiles/r05/attn_mxd_log.txt): untracked inline-asm loads are NOT usable here — under register pressure the
 // allocator copies their destination registers before the wait (stale rows; two builds wrong for that reason); the scheduler does interleave
-// the two streams, but the hardware issues VALU at ≈46 % of its rate under a dense MFMA stream of the same SIMD, so a fused segment takes
-// ≈ MFMA + 0.5 VALU, not max(MFMA, VALU); per step 6100 cycles against the band kernel's 2 x 2740.
+// the two streams, but a fused segment takes MFMA + VALU, not max(MFMA, VALU) (512 + 850 -> 1385 ticks; an enforced 1 MFMA : 8 VALU interleave
+// through sched_group_barrier changes nothing): ONE wave does not overlap its own MFMAs with its own VALU work — the overlap the band kernel
+// gets (VALU at ≈46 % under the partner's MFMA stream) needs the second wave of the SIMD; per step 6100 cycles against the band kernel's 2 x 2740.
 // Products and their order are those of the band kernel except: S^T starts from zero and the c2p band is added with the p2c band (one rounding
 // apart), the saturated tiles' K.PQ[d*] is computed once for both query tiles — results agree to one unit of the GX output format.
 #include <stdio.h>

@@ -80,7 +80,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 // 0 .. NW - 1 and writes its p2c block to the slot the block has reached; the block that enters takes the registers in place (glc_pfrag.h:
 // one asm block with tied operands) — 8 KB of position rows per wave every NW-th key tile instead of every tile (row requests 18 -> 12 KB per
 // wave and tile; the L2 -> CU path is the band kernels' busiest resource: DESIGN.md §3g).  Results bit-identical (the same products).
-template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true, bool XROT = FIXQ, bool SZ = false>
+template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true, bool XROT = FIXQ>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     static_assert(NW == 8 || NW == 4, "workgroup shapes: 8 waves x 1 per CU, 4 waves x 2 per CU");
     constexpr int LROWP = 32 * (NW + 1) + 4;            // floats per p2c image row
@@ -457,8 +457,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kc = 16 * (i >> 3) + (i & 7);
-                if constexpr (SZ) sacc[i] = 0.f;
-                else sacc[i] = xr ? c2p_l[c * LROW + (((RECOMP ? rbo : rr_base) - kc) ^ 32)] : c2p_even[-kc];
+                sacc[i] = xr ? c2p_l[c * LROW + (((RECOMP ? rbo : rr_base) - kc) ^ 32)] : c2p_even[-kc];
             }
             // ---- p2c: low block of this wave, and, one wave per tile, the high block of the last wave ----
             f32x16 bacc, bacc2;
@@ -503,9 +502,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             for (int i = 0; i < 16; i += 2) {
                 const int kc = 16 * (i >> 3) + (i & 7);
                 const int prow = 16 * (i >> 3) + 8 * ((i >> 2) & 1) + (i & 3);
-                f32x2 g = (f32x2){sacc[i], sacc[i + 1]} +
+                const f32x2 g = (f32x2){sacc[i], sacc[i + 1]} +
                                 (f32x2){img[(prow + 4 * h) * LROWP + 32 * wave + rr_base - kc], img[(prow + 1 + 4 * h) * LROWP + 32 * wave + rr_base - kc - 1]};
-                if constexpr (SZ) g += xr ? (f32x2){c2p_l[c * LROW + ((rbo - kc) ^ 32)], c2p_l[c * LROW + ((rbo - kc - 1) ^ 32)]} : (f32x2){c2p_even[-kc], c2p_even[-kc - 1]};
                 sv[i] = g[0]; sv[i + 1] = g[1];
             }
             f32x16 cacc;
@@ -616,8 +614,6 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> r9{0};
     if (a.variant & 262144) return go(attn_mx_kernel<NW, 0, false, true, true, false>, r9);     // bit 18: resident blocks, the extra block on wave t mod NW (A/B)
     if (a.variant & 131072) return go(attn_mx_kernel<NW, 0, false, true, false>, r8);     // bit 17: PQ rows requested every key tile (round 4's form; A/B)
-    static std::atomic<unsigned> r10{0};
-    if (a.variant & 1048576) return go(attn_mx_kernel<NW, 0, false, true, true, true, true>, r10);     // bit 20: S^T from zero, c2p band added with the p2c band (A/B)
     if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
 #else
     if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536 | 131072 | 262144))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";

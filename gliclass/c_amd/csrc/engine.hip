@@ -1918,7 +1918,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         set_err("attn_bench: needs a DeBERTa engine (16-bit, or fp32 with split-f16 attention) and a previous forward"); return -1.f;
     }
 #ifndef GLC_DEVELOPER
-    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288 | 1048576))) {
+    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288))) {
         set_err("attn_bench: stamped builds, timing-only builds (wrong results) and the bucket-space kernel exist in developer builds only (make DEV=1)"); return -1.f;
     }
 #endif
@@ -1934,7 +1934,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const bool mxk = (variant & 128) != 0;                    // bit 7: the MX-tile kernel (attention_mx.hip) on the MX tiles the last (MX) forward left; bits 8 / 9: its timing-only builds
     if (mxk) {
         if (!(sp && e->last_mx && e->mx_attn && w.PKm && w.PQm)) { set_err("attn_bench: the MX kernel needs a previous forward of the MX pipeline with MX attention"); return -1.f; }
-        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048 | 4096 | 16384 | 65536 | 131072 | 262144 | 1048576 | ((variant & 32768) ? 3 : 0));      // (bits 0-1 with bit 15: the role-split kernel's softmax-wave priority, developer builds)
+        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048 | 4096 | 16384 | 65536 | 131072 | 262144 | ((variant & 32768) ? 3 : 0));      // (bits 0-1 with bit 15: the role-split kernel's softmax-wave priority, developer builds)
         a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second;
     }
     const bool mxk2 = mxk && (variant & 8192) != 0;           // bit 13: the bucket-space MX kernel (attention_mx2.hip)

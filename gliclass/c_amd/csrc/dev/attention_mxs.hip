@@ -30,10 +30,10 @@
 // Saturated key tiles (delta constant: attention_wg.hip) take the same pipeline with S^T = cq + K Q^T + K PQ[d*]^T and no image.
 #include <stdio.h>
 #include <stdlib.h>
-#include "glc_common.h"
-#include "glc_kernels.h"
-#include "glc_layout.h"
-#include "glc_pfrag.h"
+#include "../glc_common.h"
+#include "../glc_kernels.h"
+#include "../glc_layout.h"
+#include "../glc_pfrag.h"
 
 namespace {
 

@@ -1469,7 +1469,13 @@ int glc_debug_fp8_range_retries(const glc_engine* e) { return e ? e->fp8_retries
 int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_off ? 1 : 0) : -1; }
 int glc_debug_activation_exponent(const glc_engine* e) { return e ? e->act_sc : 1; }
 long long glc_debug_mx_weight_bytes(const glc_engine* e) { return e ? (long long)e->mx_bytes : -1; }
-int glc_debug_set_mxs(glc_engine* e, int on) { if (!e) return -1; std::lock_guard<std::mutex> lk(e->mu); e->mxs = on != 0; return 0; }
+int glc_debug_set_mxs(glc_engine* e, int on) {
+    if (!e) return -1;
+#ifndef GLC_DEVELOPER
+    if (on) { set_err("set_mxs: the role-split attention kernel exists in developer builds only (make DEV=1)"); return -1; }
+#endif
+    std::lock_guard<std::mutex> lk(e->mu); e->mxs = on != 0; return 0;
+}
 int glc_debug_set_mx2(glc_engine* e, int on) {
     if (!e) return -1;
 #ifndef GLC_DEVELOPER
@@ -1918,8 +1924,8 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         set_err("attn_bench: needs a DeBERTa engine (16-bit, or fp32 with split-f16 attention) and a previous forward"); return -1.f;
     }
 #ifndef GLC_DEVELOPER
-    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288))) {
-        set_err("attn_bench: stamped builds, timing-only builds (wrong results) and the bucket-space kernel exist in developer builds only (make DEV=1)"); return -1.f;
+    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144 | 524288))) {
+        set_err("attn_bench: stamped builds, timing-only builds (wrong results) and the rejected attention kernels exist in developer builds only (make DEV=1)"); return -1.f;
     }
 #endif
     std::lock_guard<std::mutex> lk(e->mu);

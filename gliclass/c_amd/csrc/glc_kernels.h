@@ -209,17 +209,19 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
 // (glc_layout.h), CTX is written as GX rows; otab is the split-unit offset table.
 const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a);
 // Round 5: the same contract and bit-identical results, role-split workgroup — a matrix wave and a softmax wave per SIMD (attention_mxs.hip).
-const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a);
+// (a DEVELOPER kernel like the other rejected attention forms: csrc/dev/attention_mxs.hip — 1.32-1.36 ms against the band kernel's 1.12-1.17)
 // Round 4: the same operands and outputs, position terms in bucket (delta) space, one independent wave per query tile (csrc/dev/attention_mx2.hip:
 // measured 4-6 % slower than the band kernel — a DEVELOPER kernel since round 5, not in the product library).
 // glc_mx2_build_tables: the kernel's two tables from the distance -> delta table of a padded length; false = this table does not have the
 // structure the kernel needs (the caller keeps glc_launch_attention_mx).
 #include <vector>
 #ifdef GLC_DEVELOPER
+const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a);
 const char* glc_launch_attention_mxd(hipStream_t st, const AttnArgs& a);      // csrc/dev/attention_mxd.hip: two query tiles per wave, one wave per SIMD (round 5)
 const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a);
 bool glc_mx2_build_tables(int Sp, int P, const int32_t* dtab, std::vector<unsigned char>& idx16, std::vector<int4>& tinfo);
 #else
+inline const char* glc_launch_attention_mxs(hipStream_t, const AttnArgs&) { return "attention(mxs): the role-split kernel exists in developer builds only (make DEV=1)"; }
 inline const char* glc_launch_attention_mxd(hipStream_t, const AttnArgs&) { return "attention(mxd): the two-tiles-per-wave kernel exists in developer builds only (make DEV=1)"; }
 inline const char* glc_launch_attention_mx2(hipStream_t, const AttnArgs&) { return "attention(mx2): the bucket-space kernel exists in developer builds only (make DEV=1)"; }
 inline bool glc_mx2_build_tables(int, int, const int32_t*, std::vector<unsigned char>&, std::vector<int4>&) { return false; }

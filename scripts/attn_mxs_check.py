@@ -1,6 +1,6 @@
-"""Developer tool (GPU): the role-split MX attention (attention_mxs.hip) against the band kernel (attention_mx.hip) on the SAME MX tiles —
+"""Developer tool (GPU, make DEV=1 — scripts/dev_variant_build.sh + GLC_HIP_SO): the role-split MX attention (csrc/dev/attention_mxs.hip) against the band kernel (attention_mx.hip) on the SAME MX tiles —
 the context rows must agree to rounding (same products; only the leaving p2c block is summed in another order) — then interleaved timing on the first shape.
-usage: attn_mxs_check.py [stamps 0/1: needs make DEV=1]   env: GLC_SHAPES (BxS,...), GLC_CONFIG, GLC_REPS"""
+usage: attn_mxs_check.py [stamps 0/1]   env: GLC_SHAPES (BxS,...), GLC_CONFIG, GLC_REPS"""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -193,16 +193,17 @@ def test_product_library_has_no_path_to_timing_only_or_stamped_kernels():
         assert eng.last_mx_attention()
         cs = (C.c_double * 2)()
         assert L.glc_debug_attn_bench(eng.h, 1, 128, 0, cs) > 0                      # the shipping band kernel
-        assert L.glc_debug_attn_bench(eng.h, 1, 128 | 32768, 0, cs) > 0              # the shipping role-split kernel
-        for bits in (256, 512, 4096, 8192, 16384, 65536, 524288):                   # ablations, PV16, bucket-space kernel, spilled build, 16x16 timing build, two-tiles-per-wave kernel
+        for bits in (256, 512, 4096, 8192, 16384, 32768, 65536, 524288):                   # ablations, PV16, bucket-space kernel, spilled build, role-split kernel, 16x16 timing build, two-tiles-per-wave kernel
             assert L.glc_debug_attn_bench(eng.h, 1, 128 | bits, 0, cs) < 0, bits
             assert b"developer builds only" in L.glc_last_error(), bits
         assert L.glc_debug_attn_bench(eng.h, 1, 128, 1, cs) < 0                      # stamps
         out = (C.c_double * 8)()
         for mode in (10, 20, 30):                                                    # GY images, 16 x 16 shapes, (deleted) 128 x 128 wave tile
             assert L.glc_debug_gemm_mx_check(eng.h, 512, 768, 768, 1.0, 0.02, mode, out) != 0, mode
-        with pytest.raises(RuntimeError, match="developer builds only"):            # no silent no-op either: the switch itself refuses
+        with pytest.raises(RuntimeError, match="developer builds only"):            # no silent no-op either: the switches themselves refuse
             eng.set_mx2(True)
+        with pytest.raises(RuntimeError, match="developer builds only"):
+            eng.set_mxs(True)
     finally:
         eng.close()
 
@@ -245,10 +246,13 @@ def test_mxd_two_tiles_per_wave_attention_vs_band_kernel():
 
 def test_mxs_role_split_attention_vs_band_kernel_and_oracle():
     """Round 5: the role-split MX attention (attention_mxs.hip: a matrix wave and a softmax wave per SIMD, position blocks resident in
-    registers, the leaving p2c block as 16 x 16 quarters; opt-in) against the band kernel of the same engine.  Same products in the same
+    registers, the leaving p2c block as 16 x 16 quarters; a developer kernel: csrc/dev/, make DEV=1, skipped on the product library) against the band kernel of the same engine.  Same products in the same
     order except the leaving block (16 x 16 MFMA shapes sum their k-steps in another order): the probabilities must agree to 1e-4 (measured 3e-5), one
     row per long shape also with the CPU oracle.  Shapes: the log buckets and both saturated ends (S >= 1000), a workgroup with two
     inactive query tiles (Sp % 128 == 64), a single key tile, ragged rows (the key-length cut and the early exit of fully padded blocks)."""
+    from gliclass.c_amd import _lib
+    if not _lib.hip().glc_debug_is_developer_build():
+        pytest.skip("attention_mxs is compiled into developer builds only (make DEV=1)")
     import oracle_c
     from gliclass.c_amd import synth, weights
     from gliclass.c_amd.config import CONFIGS

@@ -25,9 +25,12 @@
 // AMDGPURewriteAGPRCopyMFMA — keep the pressure below the limit.)
 // What the measurements say (profiles/r05/attn_mxd_log.txt): untracked inline-asm loads are NOT usable here — under register pressure the
 // allocator copies their destination registers before the wait (stale rows; two builds wrong for that reason); the scheduler does interleave
-// the two streams, but a fused segment takes MFMA + VALU, not max(MFMA, VALU) (512 + 850 -> 1385 ticks; an enforced 1 MFMA : 8 VALU interleave
-// through sched_group_barrier changes nothing): ONE wave does not overlap its own MFMAs with its own VALU work — the overlap the band kernel
-// gets (VALU at ≈46 % under the partner's MFMA stream) needs the second wave of the SIMD; per step 6100 cycles against the band kernel's 2 x 2740.
+// the two streams, but a fused segment takes MFMA + VALU, not max(MFMA, VALU) (512 + 850 -> 1385 ticks) — whether hipcc places the instructions
+// (with or without sched_group_barrier pipelines) or the source does (the band -> band step below: one softmax slice between two MFMAs of different
+// accumulator chains, fenced; -disable-machine-sink keeps the slices where they are): the time moves between the segments, their sum stays at
+// ≈4500 of the step's ≈6100 cycles.  A clean loop does overlap (scripts/probes/mfma_valu_overlap_probe.hip: 8 MFMAs + 64 v_exp in one wave's stream take
+// 604 ticks where they take 256 and 560 alone; only v_pk_add_f32 refuses: 672 against 256 / 344), so the cause is in this kernel's streams, not in the
+// SIMD — 16-register accumulators and 8-register operands in the same register file as the softmax's operands are the suspect; not found this round.
 // Products and their order are those of the band kernel except: S^T starts from zero and the c2p band is added with the p2c band (one rounding
 // apart), the saturated tiles' K.PQ[d*] is computed once for both query tiles — results agree to one unit of the GX output format.
 #include <stdio.h>
@@ -303,6 +306,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             px[4 + qq] = __builtin_bit_cast(int, wl2);
         }
     };
+    // the same softmax + split in twelve slices (quad k / 3 of the 16 scores, part k % 3): the fused band step issues one slice between two MFMAs
+    auto sm_step = [&](const int k, float (&sv)[16], QState& q, f16x8 (&pf)[2], i32x8& px, f32x2& ps2) __attribute__((always_inline)) {
+        const int qq = k / 3, part = k % 3;
+        if (part == 0) {
+            // (scalar adds: v_pk_add_f32 does not overlap with MFMAs at all — scripts/probes/mfma_valu_overlap_probe.hip: 672 ticks for 8 MFMAs + 64 packed adds
+            //  where the two take 256 and 344 alone; v_add / v_fma / v_exp / the fp8 conversions hide under the matrix pipe)
+#pragma unroll
+            for (int i = 4 * qq; i < 4 * qq + 4; ++i) {
+                float d = sv[i] - q.m;
+                asm volatile("" : "+v"(d));
+                sv[i] = __builtin_amdgcn_exp2f(d);
+                ps2[i & 1] += sv[i];
+            }
+        } else if (part == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[qq >> 1][4 * (qq & 1) + e] = (f16_t)sv[4 * qq + e];
+            int wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * qq], sv[4 * qq + 1], 0, false);
+            wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * qq + 2], sv[4 * qq + 3], wh, true);
+            px[qq] = wh;
+        } else {
+            float r[4];
+            const i32x4 pfw = __builtin_bit_cast(i32x4, pf[qq >> 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pw = pfw[2 * (qq & 1) + (e >> 1)];
+                if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * qq + e]), "s"(one_f), "v"(pw));
+                else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * qq + e]), "s"(one_f), "v"(pw));
+            }
+            typedef short v2i16 __attribute__((ext_vector_type(2)));
+            v2i16 wl2 = {0, 0};
+            wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[0], r[1], 1.0f / (float)(1 << GLC_GX_SHIFT), false);
+            wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[2], r[3], 1.0f / (float)(1 << GLC_GX_SHIFT), true);
+            px[4 + qq] = __builtin_bit_cast(int, wl2);
+            if (k == 11) q.l += ps2[0] + ps2[1];
+        }
+    };
+    // single MFMAs of the four product kinds (s: f16 unit 0 .. 3, m: MX step 0 / 1)
+    auto mf = [&](f32x16& acc, const f16x8& x, const f16x8& y) __attribute__((always_inline)) { acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, acc, 0, 0, 0); };
+    auto ms_lh = [&](f32x16& acc, const i32x8& lh, const i32x8& hl) __attribute__((always_inline)) { acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(lh, hl, acc, 0, 0, 0, SC, 1, SC); };
+    auto ms_hl = [&](f32x16& acc, const i32x8& hl, const i32x8& lh) __attribute__((always_inline)) { acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hl, lh, acc, 0, 0, 1, SC, 0, SC); };
     auto pv = [&](int kt, QState& q, const f16x8 (&pf)[2], const i32x8& px) __attribute__((always_inline)) {
         VHalf v;
         load_vh(kt, 0, v);
@@ -484,10 +527,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
-                const f32x2 xa = ((f32x2){sa[i], sa[i + 1]} + (f32x2){ga[i], ga[i + 1]}) + (f32x2){ha[i], ha[i + 1]};
-                const f32x2 xb = ((f32x2){sb[i], sb[i + 1]} + (f32x2){gb[i], gb[i + 1]}) + (f32x2){hb[i], hb[i + 1]};
-                sva[i] = xa[0]; sva[i + 1] = xa[1];
-                svb[i] = xb[0]; svb[i + 1] = xb[1];
+                sva[i] = (sa[i] + ga[i]) + ha[i]; sva[i + 1] = (sa[i + 1] + ga[i + 1]) + ha[i + 1];
+                svb[i] = (sb[i] + gb[i]) + hb[i]; svb[i + 1] = (sb[i + 1] + gb[i + 1]) + hb[i + 1];
             }
         }
         const int k0 = kt * 32;
@@ -510,9 +551,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (__builtin_amdgcn_ballot_w64(mxb - B.m > RESCALE_THR) != 0ull) rescale(mxb, B);
         }
         if constexpr (ST) stamp(2);                              // seg 2: barrier X' (+ rescale)
-        // ---- the fused block, in three fenced segments (the fences bound the live ranges; inside a segment the scheduler interleaves) ----
+        // ---- the fused block ----
         f16x8 pfa[2], pfb[2];
         i32x8 pxa, pxb;
+        if constexpr (TS == T_BAND && TM == T_BAND) {
+            // Hand-placed order (profiles/r05/mfma_valu_overlap_probe.txt: one wave DOES run VALU under its own MFMAs — if the instructions alternate in
+            // program order and consecutive MFMAs belong to different accumulators; a dependent MFMA at the head of the stream stalls everything behind it).
+            // Every line below is one scheduling region: a slice of the softmax, then one MFMA of each of the chains that are open.
+#define GLC_FENCE() __builtin_amdgcn_sched_barrier(0)
+            const int t1 = kt + 1;
+            f32x2 psa = {0.f, 0.f}, psb = {0.f, 0.f};
+            load_rows(PKg, ody, pkN);                            // the rows of L_A(kt + 1): used by the c2p blocks at the step's end
+            k_tile(t1, kf);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+            f32x16 b0, b1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { b0[i] = 0.f; b1[i] = 0.f; }
+            sm_step(0, sva, A, pfa, pxa, psa); GLC_FENCE();
+            sm_step(1, sva, A, pfa, pxa, psa); GLC_FENCE();
+            // segment A: p2c block of the first resident set (X) and S^T of tile A (Y) under the softmax of tile A
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mf(b0, P0.f[u], kf.f[u]); sm_step(2 + 2 * u, sva, A, pfa, pxa, psa); GLC_FENCE();
+                mf(sa, kf.f[u], A.qf.f[u]); sm_step(3 + 2 * u, sva, A, pfa, pxa, psa); GLC_FENCE();
+            }
+            ms_hl(b0, cat8(P0.xa[0], P0.xb[0]), kf.x[0]); sm_step(10, sva, A, pfa, pxa, psa); GLC_FENCE();
+            ms_lh(sa, kf.x[0], A.qf.x[0]); sm_step(11, sva, A, pfa, pxa, psa); GLC_FENCE();
+            ms_hl(b0, cat8(P0.xa[1], P0.xb[1]), kf.x[1]);
+            ms_lh(sa, kf.x[1], A.qf.x[1]); GLC_FENCE();
+            M_band_r0(t1, eq);
+            if (kt + 1 < nkt) dma_v(kt + 1);
+            if (kt + 2 < kt_b && extra_wave(kt + 2) == wave) stage_rows(odx, px_lds + (size_t)(kt & 1) * TILEB);
+            if constexpr (ST) stamp(3);
+            GLC_FENCE();
+            // segment B: second resident set (X'), S^T of tile B (Y'), P.V of tile A (Z: o0 then o1) under the softmax of tile B
+            VHalf v;
+            load_vh(kt, 0, v);
+            band_store(img + c * LROWP + 32 * ((wave + t1) & 7), b0);
+            sm_step(0, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(b1, P1.f[0], kf.f[0]); sm_step(1, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(A.o0, v.f[0], pfa[0]); sm_step(2, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(sb, kf.f[0], B.qf.f[0]); sm_step(3, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(A.o0, v.f[1], pfa[1]); sm_step(4, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(b1, P1.f[1], kf.f[1]); sm_step(5, svb, B, pfb, pxb, psb); GLC_FENCE();
+            ms_lh(A.o0, v.x, pxa); sm_step(6, svb, B, pfb, pxb, psb); GLC_FENCE();
+            load_vh(kt, 1, v);
+            mf(sb, kf.f[1], B.qf.f[1]); sm_step(7, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(b1, P1.f[2], kf.f[2]); sm_step(8, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(A.o1, v.f[0], pfa[0]); sm_step(9, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(sb, kf.f[2], B.qf.f[2]); sm_step(10, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(A.o1, v.f[1], pfa[1]); sm_step(11, svb, B, pfb, pxb, psb); GLC_FENCE();
+            mf(b1, P1.f[3], kf.f[3]);
+            ms_lh(A.o1, v.x, pxa);
+            mf(sb, kf.f[3], B.qf.f[3]); GLC_FENCE();
+            ms_hl(b1, cat8(P1.xa[0], P1.xb[0]), kf.x[0]);
+            ms_lh(sb, kf.x[0], B.qf.x[0]); GLC_FENCE();
+            ms_hl(b1, cat8(P1.xa[1], P1.xb[1]), kf.x[1]);
+            ms_lh(sb, kf.x[1], B.qf.x[1]); GLC_FENCE();
+            M_band_r1(t1, eq);
+            if constexpr (ST) stamp(4);
+            GLC_FENCE();
+            // segment C: P.V of tile B (o0, o1), c2p blocks of both tiles (ca, cbn), the ninth block: four chains, no VALU
+            band_store(img + c * LROWP + 32 * ((wave + t1 + 4) & 7), b1);
+            band_store(ring_b + c * LROW + (xr ^ 32), cbn);      // L_B(kt + 1), computed a step ago
+            f32x16 ca;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ca[i] = 0.f; cbn[i] = 0.f; }
+            load_vh(kt, 0, v);
+            mf(ca, pkN.f[0], A.qf.f[0]); mf(cbn, pkN.f[0], B.qf.f[0]); mf(B.o0, v.f[0], pfb[0]); GLC_FENCE();
+            mf(ca, pkN.f[1], A.qf.f[1]); mf(cbn, pkN.f[1], B.qf.f[1]); mf(B.o0, v.f[1], pfb[1]); GLC_FENCE();
+            mf(ca, pkN.f[2], A.qf.f[2]); mf(cbn, pkN.f[2], B.qf.f[2]); ms_lh(B.o0, v.x, pxb); GLC_FENCE();
+            load_vh(kt, 1, v);
+            mf(ca, pkN.f[3], A.qf.f[3]); mf(cbn, pkN.f[3], B.qf.f[3]); mf(B.o1, v.f[0], pfb[0]); GLC_FENCE();
+            ms_lh(ca, pkN.x[0], A.qf.x[0]); ms_lh(cbn, pkN.x[0], B.qf.x[0]); mf(B.o1, v.f[1], pfb[1]); GLC_FENCE();
+            ms_lh(ca, pkN.x[1], A.qf.x[1]); ms_lh(cbn, pkN.x[1], B.qf.x[1]); ms_lh(B.o1, v.x, pxb); GLC_FENCE();
+            M_band_x(t1);
+            band_store(ring_a + c * LROW + (xr ^ 32), ca);
+#undef GLC_FENCE
+        } else {
         if constexpr (TS == T_BAND) load_rows(PKg, ody, pkN);   // (the rows of L_A(kt + 1): used by the c2p blocks at the step's end)
         if constexpr (TM == T_SAT) M_sat(kt + 1);
         if constexpr (TM == T_BAND) M_band_a(kt + 1);
@@ -539,6 +656,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             mm_lh_hl(pkN, A.qf, ca);                             // c2p of L_A(kt + 1)
             mm_lh_hl(pkN, B.qf, cbn);                            // c2p of L_B(kt + 2) = L_A(kt + 1)
             band_store(ring_a + c * LROW + (xr ^ 32), ca);
+        }
         }
         if constexpr (ST) stamp(5);                              // seg 5: P.V of B, c2p blocks, ring stores
         if constexpr (TM != T_NONE) wg_barrier_all();            // Y'

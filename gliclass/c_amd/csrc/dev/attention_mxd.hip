@@ -1,5 +1,5 @@
 // DeBERTa-v2/v3 disentangled self-attention on MX tiles, TWO query tiles per wave, ONE wave per SIMD, software-pipelined over the key tiles
-// (round 5, developer build: correct, 1.28 ms per launch at c3 where the band kernel of attention_mx.hip takes 1.09 — not the default).
+// (round 5, developer build: correct, 1.27 ms per launch at c3 where the band kernel of attention_mx.hip takes 1.09 — not the default).
 //
 // The band kernel (attention_mx.hip: read its header first — algebra, operand formats, the c2p rings, the shared p2c image, saturated tiles)
 // runs two independent waves per SIMD with 256 registers each; every wave reads the whole K / V^T tile and requests a whole PK block per key

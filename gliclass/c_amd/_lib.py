@@ -44,7 +44,7 @@ HIP_SYMBOLS = ["glc_device_count", "glc_last_error", "glc_engine_create", "glc_e
                "glc_engine_forward_device", "glc_engine_sync", "glc_device_malloc", "glc_device_free", "glc_memcpy_h2d",
                "glc_memcpy_d2h", "glc_timer_start", "glc_timer_stop_ms", "glc_profile_enable", "glc_profile_read",
                "glc_debug_keep_hidden", "glc_debug_get_hidden", "glc_debug_set_attention_impl", "glc_delta_table",
-               "glc_engine_config", "glc_engine_dtype", "glc_debug_gemm_bench", "glc_debug_attn_bench", "glc_engine_set_prune_last_layer", "glc_engine_set_length_buckets", "glc_plan_length_buckets", "glc_debug_last_forward_groups", "glc_debug_set_group_split", "glc_debug_last_forward_group_split", "glc_debug_set_ln_fused", "glc_debug_last_forward_ln_folded", "glc_debug_set_precision_mask", "glc_debug_set_gemm_full_lines", "glc_debug_gemm_mx_check", "glc_debug_range_retries", "glc_debug_fp8_range_retries", "glc_debug_fp8_range_sticky", "glc_debug_activation_exponent", "glc_debug_set_mx2", "glc_debug_set_mxs", "glc_debug_is_developer_build", "glc_engine_device_forward_valid", "glc_debug_mx_weight_bytes", "glc_debug_set_mx", "glc_debug_last_forward_mx", "glc_debug_last_forward_mx_attention", "glc_debug_set_stop", "glc_debug_read_workspace", "glc_debug_set_mx_attention"]
+               "glc_engine_config", "glc_engine_dtype", "glc_debug_gemm_bench", "glc_debug_attn_bench", "glc_engine_set_prune_last_layer", "glc_engine_set_length_buckets", "glc_plan_length_buckets", "glc_debug_last_forward_groups", "glc_debug_set_group_split", "glc_debug_last_forward_group_split", "glc_debug_set_ln_fused", "glc_debug_last_forward_ln_folded", "glc_debug_set_precision_mask", "glc_debug_set_gemm_full_lines", "glc_debug_gemm_mx_check", "glc_debug_range_retries", "glc_debug_fp8_range_retries", "glc_debug_fp8_range_sticky", "glc_debug_activation_exponent", "glc_debug_set_mx2", "glc_debug_is_developer_build", "glc_engine_device_forward_valid", "glc_debug_mx_weight_bytes", "glc_debug_set_mx", "glc_debug_last_forward_mx", "glc_debug_last_forward_mx_attention", "glc_debug_set_stop", "glc_debug_read_workspace", "glc_debug_set_mx_attention"]
 MODEL_SYMBOLS = ["flatten_int_array", "create_tensor", "prepare_input_tensors", "initialize_ort_api",
                  "initialize_ort_environment", "create_ort_session", "run_inference", "parallel_inference",
                  "glc_session_num_devices", "parallel_preprocess", "parallel_postprocess", "sigmoid",
@@ -107,7 +107,6 @@ def hip():
         L.glc_debug_fp8_range_sticky.argtypes = [C.c_void_p]
         L.glc_debug_activation_exponent.argtypes = [C.c_void_p]
         L.glc_debug_set_mx2.argtypes = [C.c_void_p, C.c_int]
-        L.glc_debug_set_mxs.argtypes = [C.c_void_p, C.c_int]
         L.glc_debug_mx_weight_bytes.argtypes = [C.c_void_p]
         L.glc_debug_mx_weight_bytes.restype = C.c_longlong
         L.glc_debug_set_mx.argtypes = [C.c_void_p, C.c_int]

@@ -80,8 +80,18 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 // 0 .. NW - 1 and writes its p2c block to the slot the block has reached; the block that enters takes the registers in place (glc_pfrag.h:
 // one asm block with tied operands) — 8 KB of position rows per wave every NW-th key tile instead of every tile (row requests 18 -> 12 KB per
 // wave and tile; the L2 -> CU path is the band kernels' busiest resource: DESIGN.md §3g).  Results bit-identical (the same products).
-template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true, bool XROT = FIXQ>
+// DIET (round 6, default): the band loop's look-ups and row requests without per-lane address arithmetic.  AttnArgs::mtab holds, per lane half and
+// distance entry, ONE ready-made offset of the row inside the PLANAR copy of its position table (glc_layout.h: every 16-byte piece of a row — four f16
+// units, four MX planes — at the same per-lane offset, 1 KiB apart), the PK half stored backwards; the entry index splits into a wave-uniform base that
+// moves by one block per key tile (scalar) and the lane's column, a 32-bit offset fixed at kernel entry, and the table is padded so that no index the
+// loop forms needs a clamp.  A look-up is one global_load_dword, a row block eight global_load_dwordx4 on one offset register: 33 of round 5's 245
+// vector instructions per key tile gone, one loop-carried register fewer.  With it the c2p ring holds its blocks with the table rows in DESCENDING
+// order (lane c of the PK fragment brings the row of lane 31 - c, the blocks swap ring halves): the even tile's start values S^T <- c2p come out of
+// ascending ds_read2_b32 pairs in accumulator order — 16 v_mov per two tiles gone.  Same products, same sums: bit-identical context rows.
+template <int NW, int ABL = 0, bool DIAG = false, bool RECOMP = false, bool FIXQ = true, bool XROT = FIXQ, bool DIET = true>
 __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
+    static_assert(!DIET || FIXQ, "the round-6 table serves the resident-block form only");
+    constexpr bool RV = DIET;
     static_assert(NW == 8 || NW == 4, "workgroup shapes: 8 waves x 1 per CU, 4 waves x 2 per CU");
     constexpr int LROWP = 32 * (NW + 1) + 4;            // floats per p2c image row
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -177,6 +187,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
     auto pk_of_pq = [&](int x) -> int {                  // same table row in the K layout: its slot is pi32-permuted
         const int r = (x >> 5) & 31;
         return x + ((glc_pi32(r) - r) << 5);
+    };
+    // DIET: planar copies of this head's tables and the look-ups into AttnArgs::mtab.  Entry index of block (qb, t), lane column c: J0 + c with
+    // J0 = qb - 32 t - 31 + Sp + 63 (0 <= J0 + c < NE for every t in [-1, Sp / 32 + 1], qb <= Sp + 32 NW); PQ rows: entry J0 + c (.x); PK rows:
+    // lane c brings the row of column 31 - c = backwards entry (NE - 32 - J0) + c (.y).
+    const int NE = 2 * Sp + 512;
+    const unsigned char* __restrict__ mtb = reinterpret_cast<const unsigned char*>(a.mtab);
+    const unsigned char* __restrict__ PKp = PKg + (size_t)a.nh * (a.P >> 5) * TILEB;
+    const unsigned char* __restrict__ PQp = PQg + (size_t)a.nh * (a.P >> 5) * TILEB;
+    const unsigned vl = (unsigned)((h * NE + c) * 8);
+    auto look = [&](const unsigned char* tb) -> int {      // tb: wave-uniform, kept in scalar registers (opaque: hipcc would otherwise fold it into a 64-bit per-lane address)
+        asm volatile("" : "+s"(tb));
+        return *reinterpret_cast<const int*>(tb + (size_t)vl);
+    };
+    auto rows_q = [&](int qb, int t) -> int { return look(mtb + (ptrdiff_t)(qb - 32 * t - 31 + Sp + 63) * 8); };
+    auto rows_k = [&](int qb, int t) -> int { return look(mtb + ((ptrdiff_t)(NE - 32 - (qb - 32 * t - 31 + Sp + 63)) * 8 + 4)); };
+    auto load_rows2 = [&](const unsigned char* base, const int off, MxFrag& f) __attribute__((always_inline)) {      // base: a planar copy
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f.f[s] = *reinterpret_cast<const f16x8*>(base + (size_t)(unsigned)off + s * 1024);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            f.x[m] = cat8(*reinterpret_cast<const i32x4*>(base + 4096 + (size_t)(unsigned)off + m * 2048), *reinterpret_cast<const i32x4*>(base + 4096 + (size_t)(unsigned)off + (m * 2048 + 1024)));
     };
     auto load_rows = [&](const unsigned char* base, int off, MxFrag& f) __attribute__((always_inline)) {       // gathered table rows: off = split-form offset
         // (uniform base + unsigned 32-bit lane offset + immediate: the scalar-base form of global_load, no 64-bit address arithmetic per lane)
@@ -302,7 +333,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q], sv[4 * q + 1], 0, false);
+            int wh0;
+            asm volatile("" : "=v"(wh0));      // (both halves are written below: no start value to materialise)
+            int wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q], sv[4 * q + 1], wh0, false);
             wh = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * q + 2], sv[4 * q + 3], wh, true);
             px[q] = wh;
             // lo8 = e4m3((p - f16(p)) 2^SHIFT): the residual as ONE mixed-precision FMA per value (p * 1 - f16 half, read from the packed
@@ -318,7 +351,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
                 else asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r[e]) : "v"(sv[4 * q + e]), "s"(one_f), "v"(pw));
             }
             typedef short v2i16 __attribute__((ext_vector_type(2)));
-            v2i16 wl2 = {0, 0};
+            v2i16 wl2;
+            { int wl0; asm volatile("" : "=v"(wl0)); wl2 = __builtin_bit_cast(v2i16, wl0); }
             wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[0], r[1], 1.0f / (float)(1 << GLC_GX_SHIFT), false);
             wl2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wl2, r[2], r[3], 1.0f / (float)(1 << GLC_GX_SHIFT), true);
             px[4 + q] = __builtin_bit_cast(int, wl2);
@@ -382,25 +416,38 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         {
             MxFrag pk;
             f32x16 bacc;
-            load_rows(PKg, pk_of_pq(block_x(q0, kt_a - 1)), pk);
+            if constexpr (DIET) load_rows2(PKp, rows_k(q0, kt_a - 1), pk);
+            else load_rows(PKg, pk_of_pq(block_x(q0, kt_a - 1)), pk);
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
             mm_lh_hl(pk, qf, bacc);
-            band_store(c2p_l + c * LROW + 32, bacc);            // ring half 1
-            load_rows(PKg, pk_of_pq(block_x(q0, kt_a)), pk);
+            band_store(c2p_l + c * LROW + (RV ? 0 : 32), bacc);      // ring half 1 (RV: half 0)
+            if constexpr (DIET) load_rows2(PKp, rows_k(q0, kt_a), pk);
+            else load_rows(PKg, pk_of_pq(block_x(q0, kt_a)), pk);
 #pragma unroll
             for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
             mm_lh_hl(pk, qf, bacc);
-            band_store(c2p_l + c * LROW, bacc);                 // ring half 0
+            band_store(c2p_l + c * LROW + (RV ? 32 : 0), bacc);      // ring half 0 (RV: half 1)
             wave_lds_sync();
         }
-        const float* c2p_even = c2p_l + c * LROW + rr_base;
+        // (RV: element rr of the logical [L(t) | L(t - 1)] pair sits at float 63 - rr of the ring row on even tiles, at (63 - rr) ^ 32 on odd ones)
+        const float* c2p_even = c2p_l + c * LROW + (RV ? 63 - rr_base : rr_base);
         MxFrag pq, pqx;
         PFrag pqr;                                              // FIXQ: the resident block
         int eq_n = 0;                                           // FIXQ: table offset (x) of the block that enters at the next key tile but one
         auto rows_vf = [&](int off) -> unsigned { return (unsigned)((off & ~8191) + ((off & 8191) >> 1) + h * 512); };
         auto rows_vx = [&](int off) -> unsigned { return (unsigned)(off + 4096 + h * 1024); };
-        if constexpr (FIXQ) {
+        if constexpr (FIXQ && DIET) {
+            const unsigned vo = (unsigned)rows_q(Q0 + 32 * ((wave + kt_a) & (NW - 1)), kt_a);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pqr.f[s] = *reinterpret_cast<const f16x8*>(PQp + (size_t)vo + s * 1024);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                pqr.xa[m] = *reinterpret_cast<const glc_i32x4*>(PQp + 4096 + (size_t)vo + m * 2048);
+                pqr.xb[m] = *reinterpret_cast<const glc_i32x4*>(PQp + 4096 + (size_t)vo + (m * 2048 + 1024));
+            }
+            eq_n = rows_q(Q0, kt_a + 1);
+        } else if constexpr (FIXQ) {
             const int offp = block_x(Q0 + 32 * ((wave + kt_a) & (NW - 1)), kt_a);
             const unsigned vf = rows_vf(offp), vx = rows_vx(offp);
 #pragma unroll
@@ -415,9 +462,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
         // the wave that computes the block nobody owns at key tile t: t mod NW in round 4's form; with resident blocks the wave NW - 2 - t (mod NW) —
         // never the wave that requests its entering block during the tile before (that one already issues 16 row requests, with these 24)
         auto extra_wave = [&](int t) -> int { return XROT ? ((NW - 2 - t) & (NW - 1)) : (t % NW); };
-        if (extra_wave(kt_a) == wave) load_rows(PQg, block_x(QX, kt_a), pqx);
-        int2 od_n = block_xy(q0, kt_a + 1);
-        int odx_n = block_x(QX, kt_a + 1);
+        if (extra_wave(kt_a) == wave) { if constexpr (DIET) load_rows2(PQp, rows_q(QX, kt_a), pqx); else load_rows(PQg, block_x(QX, kt_a), pqx); }
+        int2 od_n = DIET ? (int2){0, rows_k(q0, kt_a + 1)} : block_xy(q0, kt_a + 1);      // (DIET: .y = the PK rows' planar offset, .x unused)
+        int odx_n = DIET ? rows_q(QX, kt_a + 1) : block_x(QX, kt_a + 1);
         unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0, tlast = 0;
         const unsigned long long clk0 = DIAG ? __builtin_amdgcn_s_memtime() : 0, rt0 = DIAG ? __builtin_amdgcn_s_memrealtime() : 0;
         auto stamp = [&](int k) __attribute__((always_inline)) {      // time since the previous stamp goes to segment k (k < 0: start)
@@ -438,13 +485,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             stamp(0);                                           // seg 0: wait for last tile's requests
             if constexpr (FIXQ) asm volatile("" : "+v"(pqr.f[0]), "+v"(pqr.f[1]), "+v"(pqr.f[2]), "+v"(pqr.f[3]), "+v"(pqr.xa[0]), "+v"(pqr.xb[0]), "+v"(pqr.xa[1]), "+v"(pqr.xb[1]));      // (the block's uses stay behind the wait: its in-place request is not tracked by the compiler)
             const int eq = eq_n;                                // x offset of block_x(Q0, kt + 1)
-            if constexpr (FIXQ) eq_n = block_x(Q0, kt + 2);
+            if constexpr (FIXQ) eq_n = DIET ? rows_q(Q0, kt + 2) : block_x(Q0, kt + 2);
             const int jm = FIXQ ? ((wave + kt) & (NW - 1)) : wave;      // image slot of this wave's p2c block
             MxFrag pk;
             const int2 od = od_n;
             const int odx = odx_n;
-            od_n = block_xy(q0, kt + 2);
-            odx_n = block_x(QX, kt + 2);
+            if constexpr (DIET) { od_n.y = rows_k(q0, kt + 2); odx_n = rows_q(QX, kt + 2); }
+            else { od_n = block_xy(q0, kt + 2); odx_n = block_x(QX, kt + 2); }
             k_tile(kt, kf);
             float* img = p2c_img;
             f32x16 sacc;
@@ -452,12 +499,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             //  spills them — 16 of the kernel's 19 spilled registers, reloaded through the vector-memory path every second tile, 119 MB of
             //  scratch writes per launch (profiles/r04/attn_hbm_bytes.txt).  RECOMP (default since round 4): recompute them from an opaque copy of the
             //  base instead — bit-identical, 7 spilled registers left, -1.5 % per launch in the microbenchmark)
-            int rbo = rr_base;
+            int rbo = RV ? 4 * (63 - rr_base) : rr_base;
             if constexpr (RECOMP) asm volatile("" : "+v"(rbo));
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kc = 16 * (i >> 3) + (i & 7);
-                sacc[i] = xr ? c2p_l[c * LROW + (((RECOMP ? rbo : rr_base) - kc) ^ 32)] : c2p_even[-kc];
+                // (odd tiles: byte address = ((4 (63 - rr_base) + 4 kc) ^ 128) + row base: one add, one v_xad_u32 per element — hipcc's own form of
+                //  the index expression takes three)
+                if constexpr (RV) sacc[i] = xr ? *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(c2p_l + c * LROW) + (((unsigned)rbo + 4u * kc) ^ 128u)) : c2p_even[kc];
+                else sacc[i] = xr ? c2p_l[c * LROW + (((RECOMP ? rbo : rr_base) - kc) ^ 32)] : c2p_even[-kc];
             }
             // ---- p2c: low block of this wave, and, one wave per tile, the high block of the last wave ----
             f32x16 bacc, bacc2;
@@ -480,11 +530,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             mm_lh_hl(kf, qf, sacc);
             __builtin_amdgcn_sched_barrier(0);
             stamp(1);                                           // seg 1: K fragments, c2p gather, p2c + S^T MFMA issue
-            if (extra_wave(kt + 1) == wave) load_rows(PQg, odx, pqx);
+            if (extra_wave(kt + 1) == wave) { if constexpr (DIET) load_rows2(PQp, odx, pqx); else load_rows(PQg, odx, pqx); }
             __builtin_amdgcn_sched_barrier(0);
-            load_rows(PKg, od.y, pk);
+            if constexpr (DIET) load_rows2(PKp, od.y, pk);
+            else load_rows(PKg, od.y, pk);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FIXQ) pfrag_load_if(jm == NW - 1 && kt + 1 < kt_b, PQg, rows_vf(eq), rows_vx(eq), pqr);      // the block's last tile as a main slot: the block that enters takes its registers
+            if constexpr (FIXQ && DIET) pfrag_load_planar_if(jm == NW - 1 && kt + 1 < kt_b, PQp, PQp + 4096, (unsigned)eq, pqr);
+            else if constexpr (FIXQ) pfrag_load_if(jm == NW - 1 && kt + 1 < kt_b, PQg, rows_vf(eq), rows_vx(eq), pqr);      // the block's last tile as a main slot: the block that enters takes its registers
             else load_rows(PQg, od.x, pq);
             __builtin_amdgcn_sched_barrier(0);
             stamp(2);                                           // seg 2: row requests (8 waves x 16-24 KB through the CU's vector-memory path)
@@ -513,7 +565,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
             mm_lh_hl(pk, qf, cacc);                             // c2p of L(kt + 1)  [rr][query c]
             softmax_pv(sv, kt);
             stamp(6);                                           // seg 6: c2p MFMA issue, softmax, P.V issue
-            band_store(c2p_l + c * LROW + (xr ^ 32), cacc);
+            band_store(c2p_l + c * LROW + (RV ? xr : xr ^ 32), cacc);
             stamp(7);                                           // seg 7: c2p block store (waits for the matrix pipe to drain)
             if constexpr (DIAG) ++tiles;
         };
@@ -562,7 +614,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_mx_kernel(AttnArgs a) {
 
 // split-f16 units [8 hi | 8 lo] of a Q / K layout tensor (rows in tiles of 32, 64 columns: the position tables at load) -> MX tiles;
 // hl != 0: the tensor travels as (hi8 | lo8) (PQ), else as (lo8 | hi8) (PK).  One thread per (tile, lane slot r): the row's 64 columns.
-__global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int ntiles, int hl, unsigned* sat) {
+// planar != 0: the MX steps as two 16-byte planes per step ([64 lanes x first | 64 lanes x second], 1 KiB each — the form the K tiles take in the LDS ring)
+// instead of 32 bytes per lane: every 16-byte piece of a row then sits at the same per-lane offset (attention_mx.hip DIET).
+__global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int ntiles, int hl, unsigned* sat, int planar) {
     const int tile = blockIdx.x, r = threadIdx.x & 31, half = threadIdx.x >> 5;      // half: columns 32 half .. 32 half + 31
     if (tile >= ntiles) return;
     const unsigned char* st = src + (size_t)tile * 8192;
@@ -581,9 +635,9 @@ __global__ __launch_bounds__(64) void units_to_mxt_kernel(const unsigned char* _
         for (int j = 0; j < 8; ++j) lo[j] = (v[j] - (float)hi[j]) * (float)(1 << GLC_GX_SHIFT);
         const u32x2 l8 = {glc_fp8x4(lo[0], lo[1], lo[2], lo[3]), glc_fp8x4(lo[4], lo[5], lo[6], lo[7])};
         const u32x2 h8 = {glc_fp8x4(v[0], v[1], v[2], v[3]), glc_fp8x4(v[4], v[5], v[6], v[7])};
-        unsigned char* px = dt + glc_mxt_mx(0, r, 8 * g);
+        unsigned char* px = dt + (planar ? glc_mxt_mx_planar(0, r, 8 * g) : glc_mxt_mx(0, r, 8 * g));
         *reinterpret_cast<u32x2*>(px) = hl ? h8 : l8;
-        *reinterpret_cast<u32x2*>(px + 16) = hl ? l8 : h8;
+        *reinterpret_cast<u32x2*>(px + (planar ? 1024 : 16)) = hl ? l8 : h8;
     }
 }
 
@@ -613,10 +667,12 @@ template <int NW> const char* launch_mx(hipStream_t st, const AttnArgs& a) {
     static std::atomic<unsigned> r8{0};
     static std::atomic<unsigned> r9{0};
     if (a.variant & 262144) return go(attn_mx_kernel<NW, 0, false, true, true, false>, r9);     // bit 18: resident blocks, the extra block on wave t mod NW (A/B)
-    if (a.variant & 131072) return go(attn_mx_kernel<NW, 0, false, true, false>, r8);     // bit 17: PQ rows requested every key tile (round 4's form; A/B)
+    if (a.variant & 131072) return go(attn_mx_kernel<NW, 0, false, true, false, false, false>, r8);     // bit 17: PQ rows requested every key tile (round 4's form; A/B)
+    static std::atomic<unsigned> r10{0};
+    if (a.variant & 1048576) return go(attn_mx_kernel<NW, 0, false, true, true, true, false>, r10);     // bit 20: round 5's look-ups (clamped index, offsets derived per request, 32-byte MX steps) and ascending ring (A/B)
     if (a.variant & 16384) return go(attn_mx_kernel<NW, 0, false, false>, r6);     // bit 14: the odd-step gather addresses as spilled loop invariants (round 3's build; A/B)
 #else
-    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536 | 131072 | 262144))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
+    if (a.stamps || (a.variant & (256 | 512 | 4096 | 16384 | 65536 | 131072 | 262144 | 1048576))) return "attention(mx): stamped, timing-only and measurement builds exist in developer builds only (make DEV=1)";
 #endif
     return go(attn_mx_kernel<NW, 0, false, true>, r0);
 }
@@ -626,7 +682,7 @@ const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a_in) {
     AttnArgs a = a_in;
     if (!a.gx_sat) a.gx_sat = glc_gx_sat_ptr();              // fp8 range guard of the GX context rows
     if (!a.act_sc) a.act_sc = glc_gx_act_sc();               // ... and the exponent of the activation rows (engine.hip act_sc)
-    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab) return "attention(mx): null pointer";
+    if (!a.Qh || !a.Kh || !a.Vt || !a.PK || !a.PQ || !a.kbias || !a.klen || !a.kfirst || !a.CTX || !a.otab || !a.mtab) return "attention(mx): null pointer";
     if (a.B <= 0 || a.nh <= 0 || a.Sp <= 0 || a.Sp % 64 || a.H != a.nh * 64 || a.P <= 0 || a.P % 32) return "attention(mx): bad shape";
     if (a.sel_b || a.tile_flag) return "attention(mx): no row selection in this kernel";
     // workgroup shape (kernel header): 4 waves x two workgroups per CU by default; GLC_ATTN_MX_NW=8 or AttnArgs::variant bit 11: 8 waves x one (bit 10: 4)
@@ -636,8 +692,8 @@ const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a_in) {
 }
 
 // nrows rows (a multiple of 32) x 64 columns x nheads tensors in split units -> MX tiles (position tables at load)
-const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat) {
+const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat, int planar) {
     if (!src || !dst || ntiles <= 0) return "units_to_mxt: bad args";
-    hipLaunchKernelGGL(units_to_mxt_kernel, dim3(ntiles), dim3(64), 0, st, (const unsigned char*)src, (unsigned char*)dst, ntiles, hl, sat);
+    hipLaunchKernelGGL(units_to_mxt_kernel, dim3(ntiles), dim3(64), 0, st, (const unsigned char*)src, (unsigned char*)dst, ntiles, hl, sat, planar);
     return nullptr;
 }

@@ -782,7 +782,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                         const int nn = n - which * p.H, hh = nn >> 6, dd = nn & 63;
                         const int bh = b * p.nh + hh;
                         if (p.qkv_mxt) {        // MX tiles (glc_layout.h): f16 unit piece + the fp8 parts, Q as (hi8 | lo8), K as (lo8 | hi8)
-                            gx_range_note(v, 1.0f, p.gx_sat + 1);      // (tiles: the guard's second word)
+                            gx_range_note(v, 1.0f, p.gx_sat && m < p.gx_rows ? p.gx_sat + 1 : nullptr);      // (tiles: the guard's second word; no counter outside a GxScope, padding rows not counted)
                             u32x2 l8, h8;
                             gs_h8 oh;
                             gx_split8(v, 1.0f, kInvLo0, oh, l8, h8);
@@ -891,7 +891,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                     }
                     if (p.qkv_mxt) {            // V^T MX tiles: (lo8 | hi8)
                         const float x8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        gx_range_note(x8, 1.0f, p.gx_sat + 1);
+                        gx_range_note(x8, 1.0f, p.gx_sat && m < p.gx_rows ? p.gx_sat + 1 : nullptr);
                         u32x2 l8, h8;
                         gs_h8 oh;
                         gx_split8(x8, 1.0f, kInvLo0, oh, l8, h8);

@@ -132,10 +132,10 @@ struct glc_engine {
     int64_t *d_ids = nullptr, *d_mask = nullptr;
     float *Gt = nullptr, *G1t = nullptr, *G2t = nullptr, *d_logits = nullptr;   // head rows: [text | class] groups, 128-aligned
     std::map<int, int32_t*> dtabs;
+    std::map<int, int2*> mtabs;                // Sp -> the MX band kernel's ready-made row offsets (round 6; fp32 mode only): glc_kernels.h AttnArgs::mtab
     std::map<int, int2*> otabs;                // Sp -> byte offsets of the PQ / PK rows per relative distance (band kernel, 16-bit)
     std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
     std::map<int, std::pair<void*, int4*>> mx2tabs;   // Sp -> (idx16, tinfo) of attention_mx2.hip; (null, null): this table keeps the band kernel
-    bool mxs = false;                          // MX attention on the role-split kernel (attention_mxs.hip: a matrix wave + a softmax wave per SIMD; bit-identical to attention_mx.hip): GLC_ATTN_MXS, glc_debug_set_mxs
     bool mx2 = false;                          // MX attention on the bucket-space kernel (attention_mx2.hip; needs its tables) instead of the band kernel (attention_mx.hip): opt-in
                                                // (GLC_ATTN_MX2=1, glc_debug_set_mx2) — measured 4-5 % slower at c3
     // last forward
@@ -353,6 +353,25 @@ bool ensure_capacity(glc_engine* e, int B, int S, int C) {
             if (!od) return false;
             if (hipMemcpy(od, o.data(), o.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { set_err("otab upload failed"); return false; }
             e->otabs[Sp] = od;
+            if (es == 4) {
+                // MX band kernel (attention_mx.hip, round 6): the same rows as ready-made load offsets into the PLANAR tile images of the position tables
+                // (glc_layout.h) — per lane half hh and entry j (NE = 2 Sp + 512 entries: 64 clamped ones in front, the rest behind, so that no index the
+                // kernel forms needs a clamp): .x = offset of the PQ row of entry j, .y = offset of the PK row of entry NE - 1 - j (the PK half runs
+                // BACKWARDS: a lane that adds its column c to a wave-uniform base walks the PQ rows up and the PK rows down with the same per-lane
+                // register); offset = tile * 8192 + slot * 16 + hh * 512: the lane's 16 bytes of f16 unit 0; unit s at + s * 1024, MX plane k at + 4096 + k * 1024
+                const int NE = 2 * Sp + 512;
+                std::vector<int2> m((size_t)2 * NE);
+                auto dl_of = [&](int j) { const long long r = (long long)j - 64; return t[r < 0 ? 0 : (r > (long long)t.size() - 1 ? t.size() - 1 : (size_t)r)]; };
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int j = 0; j < NE; ++j) {
+                        const int dq = dl_of(j), dk = dl_of(NE - 1 - j);
+                        m[(size_t)hh * NE + j] = make_int2((dq >> 5) * 8192 + (dq & 31) * 16 + hh * 512, (dk >> 5) * 8192 + glc_pi32(dk & 31) * 16 + hh * 512);
+                    }
+                int2* md = (int2*)dmalloc(e, m.size() * sizeof(int2), false);
+                if (!md) return false;
+                if (hipMemcpy(md, m.data(), m.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { set_err("mtab upload failed"); return false; }
+                e->mtabs[Sp] = md;
+            }
         }
         // saturation points of the table: delta == P-1 for every q-k >= rsat_pos, delta == 0 for every q-k <= rsat_neg
         int rp = Sp, rn = -Sp;
@@ -769,10 +788,10 @@ bool run_forward(glc_engine* e, const int64_t* ids, const int64_t* mask, int B, 
         a.split = asplit; a.ctx_gs = mx ? 2 : (gs ? 1 : 0); a.prec = (pm >> 8) & 63;
         static const bool nosat = glc_dev_env("GLC_ATTN_NOSAT") != nullptr;      // A/B switch (developer)
         if (!nosat) { a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; }
-        a.otab = e->otabs[Sp];
+        a.otab = e->otabs[Sp]; a.mtab = e->mtabs.count(Sp) ? e->mtabs[Sp] : nullptr;
         if (mxa) { a.PK = w.PKm; a.PQ = w.PQm; e->last_mx_attn = true; a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second; }
         const bool mxa2 = mxa && e->mx2 && a.idx16 && a.tinfo;      // bucket-space kernel (round 4) when this length's table has the structure it needs
-        { Prof p(e, PC_ATTN); KCHK(mxa2 ? glc_launch_attention_mx2(st, a) : mxa ? (e->mxs ? glc_launch_attention_mxs(st, a) : glc_launch_attention_mx(st, a)) : launch_band(a), false); }
+        { Prof p(e, PC_ATTN); KCHK(mxa2 ? glc_launch_attention_mx2(st, a) : mxa ? glc_launch_attention_mx(st, a) : launch_band(a), false); }
         if (e->debug_stop == 10 * l + 1) return true;
         GemmArgs o;
         o.A = e->CTX; o.W = w.Wo; o.bias = w.bo; o.C = e->T1; o.resid = e->X; o.Mpad = Mpad; o.N = H; o.K = H;
@@ -1058,7 +1077,6 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
         e->mx = e->mx_built && !(mv && !strcmp(mv, "build"));
         if (const char* av = glc_dev_env("GLC_MX_ATTN")) e->mx_attn = atoi(av) != 0;      // developer A/B switch
         if (const char* av = glc_dev_env("GLC_DEC_ROPE_EPI")) e->dec_rope_epi = atoi(av) != 0;      // developer A/B switch
-        if (const char* av = glc_dev_env("GLC_ATTN_MXS")) e->mxs = atoi(av) != 0;         // developer A/B switch: the role-split kernel (attention_mxs.hip) / the band kernel (attention_mx.hip)
         if (const char* av = glc_dev_env("GLC_ATTN_MX2")) e->mx2 = atoi(av) != 0;         // developer A/B switch: 1 = the bucket-space kernel (attention_mx2.hip)
     }
     if (const char* gv = glc_dev_env("GLC_GS")) { const int g = atoi(gv); e->gs_mode = g < 0 ? 0 : (g > 2 ? 2 : g); }       // developer A/B switch
@@ -1199,12 +1217,16 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
                 // MX pipeline: the GX copies of the projection weights are built by the first forward that takes the pipeline (build_mx_weights);
                 // the position tables are converted here (small, and the range guard decides per layer at load)
                 if (lok && w.PKs && w.PQs) {      // the position tables as MX tiles: PQ travels as (hi8 | lo8), PK as (lo8 | hi8)
-                    w.PKm = dmalloc(e, (size_t)nh * P * 64 * es);
-                    w.PQm = dmalloc(e, (size_t)nh * P * 64 * es);
+                    // (each buffer = the tile images twice: [MX steps as 32 bytes per lane — the Q / K tile format | planar: MX steps as two 16-byte planes,
+                    //  every piece of a row at the SAME per-lane offset, glc_layout.h] — the band loop's requests read the second copy, round 6)
+                    w.PKm = dmalloc(e, 2 * (size_t)nh * P * 64 * es);
+                    w.PQm = dmalloc(e, 2 * (size_t)nh * P * 64 * es);
                     // (fp8 range guard at load: a table value beyond the e4m3 range keeps this layer's attention on split units)
                     unsigned seen = 0;
                     const char* pm = !init_range_guard(e) ? "range guard: allocation failed" : (w.PKm && w.PQm) ? glc_launch_units_to_mxt(e->stream, w.PKs, w.PKm, nh * (P / 32), 0, e->d_gxsat) : "MX position tables: allocation failed";
                     if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PQs, w.PQm, nh * (P / 32), 1, e->d_gxsat);
+                    if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PKs, (unsigned char*)w.PKm + (size_t)nh * P * 64 * es, nh * (P / 32), 0, nullptr, 1);
+                    if (!pm) pm = glc_launch_units_to_mxt(e->stream, w.PQs, (unsigned char*)w.PQm + (size_t)nh * P * 64 * es, nh * (P / 32), 1, nullptr, 1);
                     if (!pm && (hipMemcpyAsync(&seen, e->d_gxsat, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)) pm = "MX position tables: readback failed";
                     if (pm) { set_err(pm); lok = false; }
                     else if (seen != e->gxsat_seen[0]) { e->gxsat_seen[0] = seen; dfree(e, w.PKm); dfree(e, w.PQm); w.PKm = w.PQm = nullptr; }
@@ -1283,13 +1305,14 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
         glc_engine* e; bool fused, mx;
         ~Restore() { e->ln_fused = fused; e->mx = mx; }
     } restore{e, e->ln_fused, e->mx};
-    if (e->fp8_sticky_off) e->mx = false;
     // (a device-resident forward that has not been through glc_engine_sync yet: settle its range check first — this forward's own
-    //  counter readings would otherwise make the pinned copy look stale and glc_engine_sync report a range error that never happened)
+    //  counter readings would otherwise make the pinned copy look stale and glc_engine_sync report a range error that never happened;
+    //  and BEFORE the sticky switch is read: a verdict that turns it on must already keep this forward off the MX pipeline)
     if (e->fp8_device_pending) {
         HIPCHK(hipStreamSynchronize(e->stream), -1);
         settle_device_range_check(e);
     }
+    if (e->fp8_sticky_off) e->mx = false;
     unsigned sat_now[2] = {e->gxsat_seen[0], e->gxsat_seen[1]};
     bool tried_unfused = false, tried_split = false, tried_low = false;
     for (int attempt = 0; attempt < 4; ++attempt) {      // at most: MX, MX with exponent kActScLow, split-f16, norms unfused
@@ -1469,13 +1492,6 @@ int glc_debug_fp8_range_retries(const glc_engine* e) { return e ? e->fp8_retries
 int glc_debug_fp8_range_sticky(const glc_engine* e) { return e ? (e->fp8_sticky_off ? 1 : 0) : -1; }
 int glc_debug_activation_exponent(const glc_engine* e) { return e ? e->act_sc : 1; }
 long long glc_debug_mx_weight_bytes(const glc_engine* e) { return e ? (long long)e->mx_bytes : -1; }
-int glc_debug_set_mxs(glc_engine* e, int on) {
-    if (!e) return -1;
-#ifndef GLC_DEVELOPER
-    if (on) { set_err("set_mxs: the role-split attention kernel exists in developer builds only (make DEV=1)"); return -1; }
-#endif
-    std::lock_guard<std::mutex> lk(e->mu); e->mxs = on != 0; return 0;
-}
 int glc_debug_set_mx2(glc_engine* e, int on) {
     if (!e) return -1;
 #ifndef GLC_DEVELOPER
@@ -1924,7 +1940,7 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         set_err("attn_bench: needs a DeBERTa engine (16-bit, or fp32 with split-f16 attention) and a previous forward"); return -1.f;
     }
 #ifndef GLC_DEVELOPER
-    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144 | 524288))) {
+    if (stamps || (variant & (256 | 512 | 4096 | 8192 | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152))) {
         set_err("attn_bench: stamped builds, timing-only builds (wrong results) and the rejected attention kernels exist in developer builds only (make DEV=1)"); return -1.f;
     }
 #endif
@@ -1934,20 +1950,19 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
     const LayerW& w = e->layers[0];
     const bool sp = e->dtype == GLC_F32;
     AttnArgs a{e->Qh, e->Kh, e->Vt, sp ? w.PKs : w.PK, sp ? w.PQs : w.PQ, e->dtabs[Sp], e->kbias, e->klen, e->kfirst, e->CTX, B, nh, Sp, H, e->P};
-    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 123; a.otab = e->otabs[Sp]; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring; bits 4 / 5: wg kernel with / without the half-tile stagger
+    a.rsat_pos = e->dsat[Sp].first; a.rsat_neg = e->dsat[Sp].second; a.variant = variant & 123; a.otab = e->otabs[Sp]; a.mtab = e->mtabs.count(Sp) ? e->mtabs[Sp] : nullptr; a.split = sp;    // bits 0-1: per-wave kernel diagnostics; bit 3: wg kernel without the K/V ring; bits 4 / 5: wg kernel with / without the half-tile stagger
     hipStream_t st = e->stream;
     const bool wg = (variant & 4) != 0;                       // bit 2: the workgroup-shared kernel (attention_wg.hip)
     const bool mxk = (variant & 128) != 0;                    // bit 7: the MX-tile kernel (attention_mx.hip) on the MX tiles the last (MX) forward left; bits 8 / 9: its timing-only builds
     if (mxk) {
         if (!(sp && e->last_mx && e->mx_attn && w.PKm && w.PQm)) { set_err("attn_bench: the MX kernel needs a previous forward of the MX pipeline with MX attention"); return -1.f; }
-        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048 | 4096 | 16384 | 65536 | 131072 | 262144 | ((variant & 32768) ? 3 : 0));      // (bits 0-1 with bit 15: the role-split kernel's softmax-wave priority, developer builds)
+        a.PK = w.PKm; a.PQ = w.PQm; a.ctx_gs = 2; a.variant = variant & (256 | 512 | 1024 | 2048 | 4096 | 16384 | 65536 | 131072 | 262144 | 1048576 | 2097152);
         a.idx16 = e->mx2tabs[Sp].first; a.tinfo = e->mx2tabs[Sp].second;
     }
     const bool mxk2 = mxk && (variant & 8192) != 0;           // bit 13: the bucket-space MX kernel (attention_mx2.hip)
     if (mxk2 && !(a.idx16 && a.tinfo)) { set_err("attn_bench: no mx2 tables for this length"); return -1.f; }
-    const bool mxs = mxk && (variant & 32768) != 0;          // bit 15: the role-split MX kernel (attention_mxs.hip)
     const bool mxd = mxk && (variant & 524288) != 0;         // bit 19: two query tiles per wave, one wave per SIMD (csrc/dev/attention_mxd.hip; developer builds)
-    auto launch = [&]() -> const char* { return mxd ? glc_launch_attention_mxd(st, a) : mxs ? glc_launch_attention_mxs(st, a) : mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
+    auto launch = [&]() -> const char* { return mxd ? glc_launch_attention_mxd(st, a) : mxk2 ? glc_launch_attention_mx2(st, a) : mxk ? glc_launch_attention_mx(st, a) : wg ? glc_launch_attention_wg(st, e->dtype, a) : glc_launch_attention(st, e->dtype, 2, a); };
     for (int i = 0; i < 2; ++i) KCHK(launch(), -1.f);
     HIPCHK(hipEventRecord(e->t0, st), -1.f);
     for (int i = 0; i < iters; ++i) launch();
@@ -1996,22 +2011,9 @@ float glc_debug_attn_bench(glc_engine* e, int iters, int variant, int stamps, do
         if (hipMalloc((void**)&dbuf, ns * sizeof(unsigned long long)) == hipSuccess) {
             (void)hipMemsetAsync(dbuf, 0, ns * sizeof(unsigned long long), st);
             AttnArgs as = a; as.stamps = dbuf;
-            const char* m = mxd ? glc_launch_attention_mxd(st, as) : mxs ? glc_launch_attention_mxs(st, as) : mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
+            const char* m = mxd ? glc_launch_attention_mxd(st, as) : mxk2 ? glc_launch_attention_mx2(st, as) : glc_launch_attention_mx(st, as);
             (void)hipStreamSynchronize(st);
             std::vector<unsigned long long> hs(ns);
-            if (!m && mxs && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-                // role-split kernel: waves 0-3 matrix, 4-7 softmax; segments as stamped in attention_mxs.hip
-                double sm[10] = {0}, sx[10] = {0};
-                for (size_t i = 0; i < 64 * 8; ++i) for (int k = 0; k < 10; ++k) ((i & 7) < 4 ? sm : sx)[k] += (double)hs[i * 10 + k];
-                const double nm = sm[9] > 0 ? sm[9] : 1, nx = sx[9] > 0 ? sx[9] : 1;
-                double tm = 0, tx = 0;
-                for (int k = 0; k < 8; ++k) { tm += sm[k]; tx += sx[k]; }
-                fprintf(stderr, "[attn_mxs stamps] per step, matrix wave (%.0f steps): request wait + DMA issue %.0f | first half: gather, operand reads, MFMA issue, stores %.0f | stores landed + barrier A %.0f | "
-                                "second half: K DMA, c2p store, P.V, next K fragments, row requests %.0f | barrier B %.0f | total %.0f | s_memtime clock %.0f MHz\n",
-                        nm, sm[0] / nm, sm[1] / nm, sm[2] / nm, sm[3] / nm, sm[4] / nm, tm / nm, sm[8] / (64 * 4) / 10.0);
-                fprintf(stderr, "[attn_mxs stamps] per step, softmax wave (%.0f steps): barrier A %.0f | S + gather + max + exp %.0f | barrier B %.0f | sums + split + stores %.0f | total %.0f\n",
-                        nx, sx[0] / nx, sx[1] / nx, sx[2] / nx, sx[3] / nx, tx / nx);
-            } else
             if (!m && hipMemcpy(hs.data(), dbuf, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                 double s[10] = {0};
                 for (size_t i = 0; i < 64 * 8; ++i) for (int k = 0; k < 10; ++k) s[k] += (double)hs[i * 10 + k];

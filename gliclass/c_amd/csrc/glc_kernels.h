@@ -189,6 +189,7 @@ struct AttnArgs {
     const int* sel_b = nullptr; const int* sel_q = nullptr; const void* Qrow = nullptr; int nsel = 0;
     // band kernel, diagnostic build only: per (block < 64, wave) cycle sums of the band-tile segments [8] (s_memtime ticks)
     const int2* otab = nullptr;                       // band kernel: [2*Sp-1+128] byte offsets of row delta(q-k) in PQ (x) / PK (y), 64 clamped entries each side
+    const int2* mtab = nullptr;                       // MX band kernel (round 6): [2 lane halves][2 Sp + 512] ready-made row offsets into the planar copies of PQ (.x) / PK (.y, the entries backwards) that follow the tile images at PQ / PK + nh * P * 256 bytes (engine.hip)
     unsigned long long* stamps = nullptr;
     int variant = 0;                                  // band kernel diagnostics: bit 1 = one wave per SIMD (LDS padding)
     int split = 0;                                    // band kernel, fp32 mode: operands are split-f16 units (GemmArgs::qkv_split), three f16 MFMAs per product
@@ -208,26 +209,24 @@ const char* glc_launch_attention_wg(hipStream_t st, int dtype, const AttnArgs& a
 // Workgroup-shared band kernel on MX tiles (attention_mx.hip; the attention of the MX pipeline): Qh / Kh / Vt / PQ / PK are MX tiles
 // (glc_layout.h), CTX is written as GX rows; otab is the split-unit offset table.
 const char* glc_launch_attention_mx(hipStream_t st, const AttnArgs& a);
-// Round 5: the same contract and bit-identical results, role-split workgroup — a matrix wave and a softmax wave per SIMD (attention_mxs.hip).
-// (a DEVELOPER kernel like the other rejected attention forms: csrc/dev/attention_mxs.hip — 1.32-1.36 ms against the band kernel's 1.12-1.17)
+// (Round 5's role-split kernel — a matrix wave and a softmax wave per SIMD, 1.32-1.36 ms against the band kernel's 1.12-1.17 — was deleted in round 6:
+//  docs/LOG_r05.md 3g, git history.)
 // Round 4: the same operands and outputs, position terms in bucket (delta) space, one independent wave per query tile (csrc/dev/attention_mx2.hip:
 // measured 4-6 % slower than the band kernel — a DEVELOPER kernel since round 5, not in the product library).
 // glc_mx2_build_tables: the kernel's two tables from the distance -> delta table of a padded length; false = this table does not have the
 // structure the kernel needs (the caller keeps glc_launch_attention_mx).
 #include <vector>
 #ifdef GLC_DEVELOPER
-const char* glc_launch_attention_mxs(hipStream_t st, const AttnArgs& a);
 const char* glc_launch_attention_mxd(hipStream_t st, const AttnArgs& a);      // csrc/dev/attention_mxd.hip: two query tiles per wave, one wave per SIMD (round 5)
 const char* glc_launch_attention_mx2(hipStream_t st, const AttnArgs& a);
 bool glc_mx2_build_tables(int Sp, int P, const int32_t* dtab, std::vector<unsigned char>& idx16, std::vector<int4>& tinfo);
 #else
-inline const char* glc_launch_attention_mxs(hipStream_t, const AttnArgs&) { return "attention(mxs): the role-split kernel exists in developer builds only (make DEV=1)"; }
 inline const char* glc_launch_attention_mxd(hipStream_t, const AttnArgs&) { return "attention(mxd): the two-tiles-per-wave kernel exists in developer builds only (make DEV=1)"; }
 inline const char* glc_launch_attention_mx2(hipStream_t, const AttnArgs&) { return "attention(mx2): the bucket-space kernel exists in developer builds only (make DEV=1)"; }
 inline bool glc_mx2_build_tables(int, int, const int32_t*, std::vector<unsigned char>&, std::vector<int4>&) { return false; }
 #endif
 // position tables at load: split-f16 units (Q / K layout, ntiles tiles of 32 rows x 64 columns) -> MX tiles; hl: (hi8 | lo8) order (PQ), else (lo8 | hi8) (PK)
-const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat = nullptr);   // sat: fp8 range guard counter (glc_common.h)
+const char* glc_launch_units_to_mxt(hipStream_t st, const void* src, void* dst, int ntiles, int hl, unsigned* sat = nullptr, int planar = 0);   // sat: fp8 range guard counter (glc_common.h)
 
 #include <atomic>
 // CU count of the CURRENT device, cached per device ordinal (a session may span GPUs of different sizes)

@@ -51,6 +51,11 @@ __host__ __device__ __forceinline__ size_t glc_mxt_f16(int tile, int slot, int e
 __host__ __device__ __forceinline__ size_t glc_mxt_mx(int tile, int slot, int e0) {
     return (size_t)tile * GLC_MXT_BYTES + 4096 + (e0 >> 5) * 2048 + (32 * ((e0 >> 4) & 1) + slot) * 32 + 8 * ((e0 >> 3) & 1);
 }
+// planar form of a position table's MX steps (round 6; attention_mx.hip DIET): step m as two 1-KiB planes [64 lanes x 16 B first | 64 lanes x 16 B
+// second] — the piece of lane 32 h + slot at + lane * 16, so the f16 unit piece (glc_mxt_f16) and all four MX pieces of a row share one per-lane offset
+__host__ __device__ __forceinline__ size_t glc_mxt_mx_planar(int tile, int slot, int e0) {
+    return (size_t)tile * GLC_MXT_BYTES + 4096 + (e0 >> 5) * 2048 + (32 * ((e0 >> 4) & 1) + slot) * 16 + 8 * ((e0 >> 3) & 1);
+}
 // V^T: the 8 consecutive keys k0 .. k0 + 7 (k0 % 8 == 0, inside key tile `tile`) of row dd
 __host__ __device__ __forceinline__ size_t glc_mxt_v_f16(int tile, int dd, int k0) {
     const int kg = (k0 & 31) >> 3;

@@ -1,4 +1,4 @@
-// Position blocks that stay in registers over several key tiles (attention_mx.hip, attention_mxs.hip; round 5).
+// Position blocks that stay in registers over several key tiles (attention_mx.hip; round 5).
 #pragma once
 #include "glc_common.h"
 
@@ -18,6 +18,18 @@ __device__ __forceinline__ void pfrag_load_if(int cond, const unsigned char* bas
                  ".Lpfskip%=:"
                  : [f0] "+v"(f.f[0]), [f1] "+v"(f.f[1]), [f2] "+v"(f.f[2]), [f3] "+v"(f.f[3]), [a0] "+v"(f.xa[0]), [b0] "+v"(f.xb[0]), [a1] "+v"(f.xa[1]), [b1] "+v"(f.xb[1])
                  : [c] "s"(__builtin_amdgcn_readfirstlane(cond)), [vf] "v"(vf), [vx] "v"(vx), [b] "s"(base)
+                 : "scc", "memory");
+}
+// the same from the PLANAR copy of a table (round 6): all eight pieces on ONE offset register, f16 units from `b`, the MX planes from `bx` = b + 4096
+__device__ __forceinline__ void pfrag_load_planar_if(int cond, const unsigned char* b, const unsigned char* bx, unsigned vo, PFrag& f) {
+    asm volatile("s_cmp_eq_u32 %[c], 0\n\ts_cbranch_scc1 .Lpfskip%=\n\t"
+                 "global_load_dwordx4 %[f0], %[vo], %[b]\n\tglobal_load_dwordx4 %[f1], %[vo], %[b] offset:1024\n\t"
+                 "global_load_dwordx4 %[f2], %[vo], %[b] offset:2048\n\tglobal_load_dwordx4 %[f3], %[vo], %[b] offset:3072\n\t"
+                 "global_load_dwordx4 %[a0], %[vo], %[bx]\n\tglobal_load_dwordx4 %[b0], %[vo], %[bx] offset:1024\n\t"
+                 "global_load_dwordx4 %[a1], %[vo], %[bx] offset:2048\n\tglobal_load_dwordx4 %[b1], %[vo], %[bx] offset:3072\n"
+                 ".Lpfskip%=:"
+                 : [f0] "+v"(f.f[0]), [f1] "+v"(f.f[1]), [f2] "+v"(f.f[2]), [f3] "+v"(f.f[3]), [a0] "+v"(f.xa[0]), [b0] "+v"(f.xb[0]), [a1] "+v"(f.xa[1]), [b1] "+v"(f.xb[1])
+                 : [c] "s"(__builtin_amdgcn_readfirstlane(cond)), [vo] "v"(vo), [b] "s"(b), [bx] "s"(bx)
                  : "scc", "memory");
 }
 // every vector-memory request of this wave has landed; the uses of both position blocks stay behind the wait.  (NOT a counted wait that

@@ -144,11 +144,6 @@ class Engine:
         """exponent of the MX pipeline's activation rows: 0, or -5 once a forward left the fp8 range (the guard's first answer)"""
         return int(self.L.glc_debug_activation_exponent(self.h))
 
-    def set_mxs(self, on):
-        """developer builds (make DEV=1): MX attention on the role-split kernel (csrc/dev/attention_mxs.hip) or on the band kernel; the product library refuses on=True; same results to rounding (<= 1e-4 of a row's scale)"""
-        if self.L.glc_debug_set_mxs(self.h, int(bool(on))) != 0:
-            raise RuntimeError(self.L.glc_last_error().decode())
-
     def set_mx2(self, on):
         """developer builds (make DEV=1): MX attention on the bucket-space kernel (csrc/dev/attention_mx2.hip) or on the band kernel; the product library refuses on=True"""
         if self.L.glc_debug_set_mx2(self.h, int(bool(on))) != 0:

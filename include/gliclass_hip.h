@@ -163,7 +163,6 @@ int glc_debug_last_forward_mx(const glc_engine* e);
 int glc_debug_last_forward_mx_attention(const glc_engine* e);   /* 1: the last forward's attention ran on MX tiles (two MFMA times per product) */
 int glc_debug_set_mx_attention(glc_engine* e, int on);
 long long glc_debug_mx_weight_bytes(const glc_engine* e);  /* bytes of the GX weight copies (0 until a forward has taken the MX pipeline: they are built then) */
-int glc_debug_set_mxs(glc_engine* e, int on);              /* developer builds (make DEV=1): role-split kernel (csrc/dev/attention_mxs.hip, slower: DESIGN.md 3g) / band kernel (default); -1 for on != 0 in the product library */
 int glc_debug_set_mx2(glc_engine* e, int on);              /* developer builds (make DEV=1): bucket-space kernel (csrc/dev/attention_mx2.hip) / band kernel (default); -1 for on != 0 in the product library */     /* MX pipeline: attention on MX tiles (default) / on split-f16 units */
 /* Developer: stop forwards after a stage and read workspace rows decoded to fp32 (engine.hip). */
 int glc_debug_set_stop(glc_engine* e, int stage);

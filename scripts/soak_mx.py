@@ -13,8 +13,6 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
 cname = sys.argv[2] if len(sys.argv) > 2 else "base"
 cfg = CONFIGS[cname]
 e = Engine.from_spec(cfg, f"synthetic:{cname}:42", dtype="f32")
-if os.environ.get("GLC_SOAK_MXS"):          # developer builds: the role-split attention kernel (csrc/dev/attention_mxs.hip) instead of the band kernel
-    e.set_mxs(True); print("attention: attention_mxs.hip")
 if os.environ.get("GLC_SOAK_MX2"):          # the bucket-space attention kernel (attention_mx2.hip) instead of the band kernel
     e.set_mx2(True); print("attention: attention_mx2.hip")
 rng = np.random.RandomState(20261004)

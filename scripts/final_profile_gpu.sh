@@ -21,8 +21,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace --
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 $BENCH > "$OUT/pmc_fetch.log" 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 $BENCH > "$OUT/pmc_write.log" 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o pmc -- python3 $BENCH > "$OUT/pmc_sq.log" 2>&1; echo "sq rc=$?"
+# (round 6, review item 4) second SQ pass + the clock: what the pipe waits for, per kernel — issue stalls, LDS, vector memory, MFMA / VALU co-execution
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -o pmc -- python3 $BENCH > "$OUT/pmc_sq2.log" 2>&1; echo "sq2 rc=$?"
 cd "$REPO"
 python3 scripts/summarize_prof.py "$OUT" f32 base:64:1024 "$COMMIT" > "$OUT/summary.txt" 2>&1
+python3 scripts/pipe_account.py "$OUT" "$COMMIT" > "$OUT/pipe_account.txt" 2>&1
 python3 - "$OUT" "$COMMIT" > "$OUT/pmc_sq.txt" <<'PY'
 import csv, glob, os, sys, re
 from collections import defaultdict
@@ -41,7 +44,7 @@ for k, cs in sorted(acc.items()):
         print(f"   {c:34s} avg/launch = {tot/n:16.0f}   ({n} launches)")
 PY
 find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
-rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
+rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_sq2"
 # (round 5) the opt-in 16-bit throughput mode's FETCH / WRITE passes of the SAME build: the f16 entry of traffic.json (it used to be a round-1 pass)
 mkdir -p "$OUT/f16"
 cd /tmp
@@ -68,4 +71,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c5" -o trace
 cd "$REPO"
 find "$OUT/trace_c5" -name "*kernel_stats.csv" -exec cp {} "$OUT/c5_kernel_stats.csv" \;
 rm -rf "$OUT/trace_c5"
-head -12 "$OUT/summary.txt"; tail -c 400 "$OUT/bench_c3.json"
+# (round 6, review item 6) BASELINE.json's c4 as ONE GPU sees it: gliclass-large, 32 rows of 1024 — bench line + kernel stats
+python3 bench.py --config large --batch 32 --cpu-seqs 0 --throughput-dtype none > "$OUT/bench_c4_shard.json" 2> "$OUT/bench_c4_shard.err"; echo "c4 shard bench rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c4" -o trace -- python3 $REPO/bench.py --config large --batch 32 --steps 2 --warmup 1 --cpu-seqs 0 --no-profile --throughput-dtype none > "$OUT/trace_c4.log" 2>&1; echo "c4 trace rc=$?"
+cd "$REPO"
+find "$OUT/trace_c4" -name "*kernel_stats.csv" -exec cp {} "$OUT/c4_shard_kernel_stats.csv" \;
+rm -rf "$OUT/trace_c4"
+head -12 "$OUT/summary.txt"; cat "$OUT/pipe_account.txt"; tail -c 400 "$OUT/bench_c3.json"

@@ -43,9 +43,6 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 #ifndef GLC_GX_W_AUX
 #define GLC_GX_W_AUX 0
 #endif
-#ifndef GLC_GX_RSPLIT
-#define GLC_GX_RSPLIT 0
-#endif
 // AUX: the cache-policy bits of the request (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
 template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
@@ -152,16 +149,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     auto sub = [&](const int s, const int odd) __attribute__((always_inline)) {
         // ---- phase A ----
         if (pm == 2) __builtin_amdgcn_s_setprio(2);
-#if GLC_GX_RSPLIT
-        // Requests of group s + 1 spread evenly over the step's four barrier slots, whole lines (round 6 experiment): the early wave group asks for its
-        // A rows in E and its W rows in O, the late group (one slot behind) for its W rows in E and its A rows in O — 16 KiB enter the vector-memory
-        // path in every slot instead of 32 KiB in two of four.  Deadlines: W rows are read by BOTH groups (the early one first, at its next E), A rows
-        // 128-255 by the late group only: early group — everything landed before the barrier that ends its O; late group — its W rows before the
-        // barrier that ends its O's load phase (a counted wait: its A rows, younger, stay in flight), its A rows before the barrier that ends its O.
-        if (s + 1 < ng) { if ((wm == 0) != (odd != 0)) stage_a(s + 1); else stage_w(s + 1); }
-#else
         if (!odd && s + 1 < ng && 0 != 5) stage_fl(s + 1);      // (ABL 4 / 5 / 6: timing-only builds — no fragment reads / no DMA / no MFMAs; wrong results)
-#endif
         {
             const unsigned char* sa = smem256x + ((2 * s) & (NSLOT - 1)) * STAGE + arow;
             const unsigned char* sw = smem256x + ((2 * s + 1) & (NSLOT - 1)) * STAGE + wrow;
@@ -183,13 +171,8 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
                 for (int i = 0; i < 4; ++i) xa[i] = ld32(sa + i * 32 * LINE, cx0, cx1);      // [a_lo8 a_hi8 | a_lo8 a_hi8]
             }
         }
-#if GLC_GX_RSPLIT
-        if (odd && wm == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
         if (odd) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if (pm == 2) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
@@ -217,9 +200,6 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         }
         if (pm == 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-#if GLC_GX_RSPLIT
-        if (odd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_s_barrier();
     };
     for (int s = 0; s < ng; ++s) { sub(s, 0); sub(s, 1); }

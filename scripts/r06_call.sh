@@ -1,4 +1,3 @@
 OUT=gpurun_out/r06; mkdir -p $OUT
-GLC_HIP_SO=$PWD/gliclass/c_amd/variants/libgliclass_hip_persist.so timeout -k 10 600 python3 -m pytest tests/test_gpu_mx.py -q -x -k "epilogue or gemm" 2>&1 | tail -3
-bash scripts/ab_so.sh - gliclass/c_amd/variants/libgliclass_hip_persist.so > $OUT/ab_persist.txt 2>&1; cat $OUT/ab_persist.txt
-GLC_HIP_SO=$PWD/gliclass/c_amd/variants/libgliclass_hip_persist.so timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --cpu-seqs 4 --throughput-dtype none 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('persist parity', d['cpu_baseline'].get('gpu_vs_cpu_max_prob_err'), d['parity_ok'], d['value'])"
+V=gliclass/c_amd/variants
+bash scripts/ab_so.sh - $V/libgliclass_hip_w128.so $V/libgliclass_hip_w128a1.so $V/libgliclass_hip_w128a2.so $V/libgliclass_hip_w128a4.so $V/libgliclass_hip_w128a7.so > $OUT/ab_w128_abl.txt 2>&1; cat $OUT/ab_w128_abl.txt

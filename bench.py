@@ -44,7 +44,7 @@ BAR = 1e-3                                                     # /root/reference
 
 
 def kernel_flops(cfg, B, S):
-    """Algorithmic FLOPs of ONE launch of each kernel class (SURVEY.md §8d terms; DESIGN.md §Kernels)."""
+    """Algorithmic FLOPs of ONE launch of each kernel class (SURVEY.md §8d terms; DESIGN.md §4)."""
     H, I, P = cfg.hidden, cfg.inter, 2 * cfg.att_span
     M = B * S
     if cfg.backbone == 1:          # decoder-style backbone (Qwen2 arithmetic)
@@ -490,7 +490,7 @@ def main():
                    "gathered_rows": [int(v) for v in (full[:, 0] / 16).tolist()] if args.scaling == "strong" else None}
     else:
         h = runner.h
-        # HIP-event cross-check of the same loop on this rank's stream (DESIGN.md §Measurement)
+        # HIP-event cross-check of the same loop on this rank's stream (DESIGN.md §7)
         hipl.glc_timer_start(h)
         for _ in range(args.steps):
             runner.step()
@@ -618,7 +618,7 @@ def main():
             tdt = args.throughput_dtype
             if cpu and world == 1 and tdt != "none" and tdt != args.dtype:
                 # The opt-in 16-bit throughput mode on the same workload: reported beside the headline number, never instead of
-                # it — its operand rounding alone can exceed the 1e-3 bar on these random-weight models.
+                # it — its operand rounding alone can exceed the 1e-3 bar on these random-weight models (docs/LOG_r01-r05.md §2).
                 runner.close()
                 r2 = EngineRunner(args, cfg, W, local_rank, tdt, ids, mask)
                 for _ in range(2):

@@ -577,7 +577,7 @@ const char* glc_launch_attention(hipStream_t st, int dtype, int impl, const Attn
         if (dtype == GLC_DT_F32) {
             if (a.stamps) return "attention: the stamped build exists for f16 only";
             // The lean (in-place reload) loop with split fragments: round 1 measured it 5 % faster but WRONG (err 5e-2).  Root cause (round 2,
-            // DESIGN.md section 2): a wait count that hipcc leaves out in THIS instantiation once its SLP vectoriser has formed packed-fp32
+            // docs/LOG_r01-r05.md section 2): a wait count that hipcc leaves out in THIS instantiation once its SLP vectoriser has formed packed-fp32
             // (v_pk_*_f32) instructions — the same object is correct with -mllvm -amdgpu-waitcnt-forcezero, with packed fp32 disabled, or
             // with -fno-slp-vectorize, which is how this translation unit is built (Makefile); in that build the instantiation passes the
             // whole fp32 parity suite (GLC_ATTN_WG=0 GLC_ATTN_SPLIT_LEAN=1).  It stays a diagnostic: the split mode's attention is

@@ -72,14 +72,14 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
 
 // ABL: timing-only builds (wrong results; AttnArgs::variant bits 8 / 9 through glc_debug_attn_bench): 1 = without the block-scaled MFMAs,
 // 2 = without the fp8 conversion of the probabilities.  ABL = 3 is a MEASUREMENT build with right results at lower precision: P and V^T at
-// single f16 in the P.V product (no P split, no scaled MFMA there) — what the precision budget's one affordable cut buys in
+// single f16 in the P.V product (no P split, no scaled MFMA there) — what the precision budget's one affordable cut (docs/LOG_r01-r05.md §2) buys in
 // time; GLC_ATTN_PV16=1 or variant bit 12, never the default.
 // DIAG: s_memtime stamps at the phase boundaries of a band tile, summed per wave in SGPRs (glc_debug_attn_bench prints them; the stamps
 // pin the instruction order at each boundary, so the stamped build is slower than the one it describes).
 // FIXQ (round 5, default): a wave keeps ITS PQ block (rel-block g = slot - key tile, g mod NW == wave) in registers while it is image slot
 // 0 .. NW - 1 and writes its p2c block to the slot the block has reached; the block that enters takes the registers in place (glc_pfrag.h:
 // one asm block with tied operands) — 8 KB of position rows per wave every NW-th key tile instead of every tile (row requests 18 -> 12 KB per
-// wave and tile; the L2 -> CU path is the band kernels' busiest resource: DESIGN.md §3g).  Results bit-identical (the same products).
+// wave and tile; the L2 -> CU path is the band kernels' busiest resource: docs/LOG_r01-r05.md §3g).  Results bit-identical (the same products).
 // DIET (round 6, default): the band loop's look-ups and row requests without per-lane address arithmetic.  AttnArgs::mtab holds, per lane half and
 // distance entry, ONE ready-made offset of the row inside the PLANAR copy of its position table (glc_layout.h: every 16-byte piece of a row — four f16
 // units, four MX planes — at the same per-lane offset, 1 KiB apart), the PK half stored backwards; the entry index splits into a wave-uniform base that

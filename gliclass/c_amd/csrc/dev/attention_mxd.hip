@@ -4,7 +4,7 @@
 // The band kernel (attention_mx.hip: read its header first — algebra, operand formats, the c2p rings, the shared p2c image, saturated tiles)
 // runs two independent waves per SIMD with 256 registers each; every wave reads the whole K / V^T tile and requests a whole PK block per key
 // tile for its ONE query tile: ≈37 KB of LDS traffic and 10 KB of row requests per (query tile, key tile) — the LDS array and the matrix pipe
-// are equally loaded ("the budgets").  Here a workgroup is four waves, one per SIMD with the SIMD's whole register file (512),
+// are equally loaded (docs/LOG_r01-r05.md §3g, "the budgets").  Here a workgroup is four waves, one per SIMD with the SIMD's whole register file (512),
 // and wave w owns the query tiles A = 2 w and B = 2 w + 1 of 256 consecutive queries:
 //   * K fragments are read from LDS once per key tile for both query tiles, the key bias likewise (V^T: per 32-row half and query tile — both
 //     halves resident cost 16 registers more than the fused step has);

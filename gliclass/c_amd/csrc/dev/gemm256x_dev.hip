@@ -3,7 +3,7 @@
 //   GY    e2m3 cross terms with per-16-element block scales (round 4: correct in every epilogue, +-0 ... -4 % on real data)
 //   Z16   the main loop on the 16 x 16 MFMA shapes (round 4: correct, -8 ... +5 %)
 //   DIAG  s_memtime stamps of the main loop; ABL 4-8: timing-only builds (WRONG results)
-// (W128, the one-wave-per-SIMD 128 x 128 wave tile, was deleted in round 5: DESIGN.md §9 post-mortem.)
+// (W128, the one-wave-per-SIMD 128 x 128 wave tile, was deleted in round 5: docs/LOG_r01-r05.md §9 post-mortem.)
 // Entry: glc_launch_gemm256x_dev — reached from glc_launch_gemm256x only when a developer field of GemmArgs asks for one of these.
 #define glc_launch_gemm256x glc_launch_gemm256x_dev
 #define glc_gemm256x_supported glc_gemm256x_supported_dev
@@ -938,14 +938,14 @@ __global__ __launch_bounds__(512, 2) void gemm256x_qkvr_kernel(GemmArgs p, int n
 }
 
 template <int EPI, bool VMODE, bool DIAG = false, int ABL = 0, bool GY = false, bool Z16 = false> const char* launch_x(hipStream_t st, const GemmArgs& a, int n_tile0, int ntn) {
-#ifdef GLC_DEVELOPER      // the 16 x 16 MFMA shapes (Z16): correct in every epilogue, -8 ... +5 % against the 32 x 32 loop — developer builds only
+#ifdef GLC_DEVELOPER      // the 16 x 16 MFMA shapes (Z16): correct in every epilogue, -8 ... +5 % against the 32 x 32 loop (docs/LOG_r01-r05.md §9) — developer builds only
     if constexpr (!DIAG && ABL == 0 && !GY && !Z16) {
         if (a.z16 && !a.gy && a.K % 64 == 0 && !a.stamps && a.prio_mode < 4) return launch_x<EPI, VMODE, false, 0, false, true>(st, a, n_tile0, ntn);
     }
 #endif
     if constexpr (!DIAG && ABL == 0 && !GY && !Z16) {
         if (a.gy) {
-#ifdef GLC_DEVELOPER      // GY images (e2m3 parts with block scales): built and verified, not faster under the chip's power envelope — developer builds only
+#ifdef GLC_DEVELOPER      // GY images (e2m3 parts with block scales): built and verified, not faster under the chip's power envelope (docs/LOG_r01-r05.md §6) — developer builds only
             if constexpr (EPI == EPI_BIAS && !VMODE) { if (a.stamps) return launch_x<EPI, VMODE, true, 0, true>(st, a, n_tile0, ntn); }
             return launch_x<EPI, VMODE, false, 0, true>(st, a, n_tile0, ntn);
 #else

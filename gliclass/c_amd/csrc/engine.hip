@@ -137,7 +137,7 @@ struct glc_engine {
     std::map<int, std::pair<int, int>> dsat;   // Sp -> (rsat_pos, rsat_neg)
     std::map<int, std::pair<void*, int4*>> mx2tabs;   // Sp -> (idx16, tinfo) of attention_mx2.hip; (null, null): this table keeps the band kernel
     bool mx2 = false;                          // MX attention on the bucket-space kernel (attention_mx2.hip; needs its tables) instead of the band kernel (attention_mx.hip): opt-in
-                                               // (GLC_ATTN_MX2=1, glc_debug_set_mx2) — measured 4-5 % slower at c3
+                                               // (GLC_ATTN_MX2=1, glc_debug_set_mx2) — measured 4-5 % slower at c3 (docs/LOG_r01-r05.md §3f)
     // last forward
     int lastB = 0, lastS = 0, lastSp = 0;
     // debug
@@ -600,7 +600,7 @@ bool run_forward_decoder(glc_engine* e, const int64_t* ids, const int64_t* mask,
     }
     e->last_gs = gs;
     void *X = e->X, *Xn = e->X2;
-    // RMSNorm folded away (group-split pipeline, e->ln_fused): the residual stream is kept as RAW group-split rows plus
+    // RMSNorm folded away (group-split pipeline, e->ln_fused; docs/LOG_r01-r05.md §3d): the residual stream is kept as RAW group-split rows plus
     // (0, rstd) per row — statsA for the buffer X points at, statsB for the other — the projections run on weights with the RMSNorm gain
     // folded in and scale their accumulators by rstd in the epilogue; the residual GEMMs emit the partials of the next statistics.
     const bool rnf = gs && e->ln_fused && e->fused_swiglu && L > 0 && e->dlayers[0].Wqkvf && e->dlayers[0].Wguf && e->statsA && e->statsB && e->ln_part;
@@ -1065,7 +1065,7 @@ glc_engine* glc_engine_create(const glc_model_config* cfg, const float* const* t
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->dec_split = dtype == GLC_F32 && cfg->backbone == GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     { const char* av = getenv("GLICLASS_F32_ATTN"); e->attn_split = dtype == GLC_F32 && cfg->backbone != GLC_BACKBONE_DECODER && !(av && !strcmp(av, "native")); }
     if (const char* lv = glc_dev_env("GLC_LNF")) e->ln_fused = atoi(lv) != 0;      // developer A/B switch
-    // MX cross-term pipeline — the default arithmetic of the large forwards of the default mode since round 3: the
+    // MX cross-term pipeline (docs/LOG_r01-r05.md §3e) — the default arithmetic of the large forwards of the default mode since round 3: the
     // projections of the full layers run a_hi*w_hi in f16 MFMAs and both cross terms in one block-scaled fp8 MFMA (per-label
     // probabilities within 1e-4 of the split-f16 arithmetic, measured; the bar is 1e-3).  GLICLASS_MX=0: split-f16 projections
     // everywhere (three f16 MFMAs per product, ~1e-5); GLICLASS_MX=build: GX weight copies built, pipeline off until glc_debug_set_mx.
@@ -1293,7 +1293,7 @@ static int forward_one(glc_engine* e, const int64_t* ids, const int64_t* mask, i
     HIPCHK(hipMemcpyAsync(e->d_mask, mask, nb, hipMemcpyHostToDevice, e->stream), -1);
     // Every matrix product runs on f16 / bf16 MFMA operands (the fp32 mode as split-f16 pairs), so an activation beyond the operand
     // range (|x| > 65504 for f16) turns into inf / NaN silently.  A result the reference's fp32 graph would not produce must not be
-    // returned as if it were one.  With the norm folded into the GEMMs the RAW residual stream is such an operand — a
+    // returned as if it were one.  With the norm folded into the GEMMs (docs/LOG_r01-r05.md §3d) the RAW residual stream is such an operand — a
     // pre-norm decoder's massive-activation channels can leave the f16 range although every normalised row is tiny — so a non-finite
     // result of a folded forward is retried ONCE with the norms as kernels of their own (residual stream plain fp32, only normalised
     // rows split); what is still non-finite then fails the call.  (fp32 mode: GLICLASS_F32_GEMM=native GLICLASS_F32_ATTN=native run the fp32 MFMAs.)
@@ -1718,7 +1718,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
     which %= 1000;
     const int which_in = which;
     if (which >= 100) which %= 100;
-    if (which == 14) { set_err("gemm_bench: the one-wave-per-SIMD 128 x 128 wave tile (which = 14) was deleted in round 5 (DESIGN.md section 9)"); return -1.f; }
+    if (which == 14) { set_err("gemm_bench: the one-wave-per-SIMD 128 x 128 wave tile (which = 14) was deleted in round 5 (docs/LOG_r01-r05.md section 9)"); return -1.f; }
     const bool z16b = which == 13;                    // the GX kernel with the 16 x 16 MFMA shapes
     const bool gyb = which == 11 || which == 12;      // the same kernel on GY rows (e2m3 parts with block scales); 12: plus one stamped launch
     const bool mxb = which == 9 || which == 10 || gyb || z16b;      // the MX cross-term kernel on GX rows (gemm256x.hip); 10: plus one stamped launch
@@ -1805,7 +1805,7 @@ float glc_debug_gemm_bench(glc_engine* e, int M, int N, int K, int epi, int iter
  * out[0] = max |mx - gs|, out[1] = max |gs|, out[2] = rms(mx - gs), out[3] = rms(gs) over the decoded outputs (mode 2: + the ln_part
  * sums in out[4] = max |diff|).  Returns 0 or < 0. */
 int glc_debug_gemm_mx_check(glc_engine* e, int M, int N, int K, float a_amp, float w_amp, int mode, double* out) {
-    if (mode >= 30) { set_err("gemm_mx_check: mode + 30 (the one-wave-per-SIMD 128 x 128 wave tile) was deleted in round 5 (DESIGN.md section 9)"); return -1; }
+    if (mode >= 30) { set_err("gemm_mx_check: mode + 30 (the one-wave-per-SIMD 128 x 128 wave tile) was deleted in round 5 (docs/LOG_r01-r05.md section 9)"); return -1; }
     const bool z16 = mode >= 20;         // mode + 20: the MX leg's main loop on the 16 x 16 MFMA shapes (GemmArgs::z16)
     if (z16) mode -= 20;
     const bool gy = mode >= 10;          // mode + 10: the MX leg on GY rows (e2m3 parts with block scales) instead of GX rows

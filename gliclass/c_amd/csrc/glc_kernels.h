@@ -10,7 +10,7 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_QKV = 3,
        EPI_SWIGLU = 4,     // gemm256s / gemm256x: W rows interleave 16 gate / 16 up features; C [Mpad, N/2] = silu(gate) * up
        EPI_QKVR = 5 };     // gemm256x only, decoder backbone: RoPE + softmax scale + the MX tiles of decoder_mx.hip written by the epilogue (rope_cs ..)
 
-// Developer A/B switches (GLC_* environment variables: kernel variants kept for same-box comparisons) are read only by a
+// Developer A/B switches (GLC_* environment variables: kernel variants kept for same-box comparisons, docs/LOG_r01-r05.md §7) are read only by a
 // library built with -DGLC_DEVELOPER (make DEV=1); the product library reads the documented GLICLASS_* knobs and nothing else.
 #include <stdlib.h>
 inline const char* glc_dev_env(const char* name) {
@@ -55,7 +55,7 @@ struct GemmArgs {
     // QKV (gemm256s), pruned last layer: one byte per 32-row tile of the [Mpad] rows; a workgroup of the Q third whose 256 rows hold no
     // flagged tile returns at once (only the query tiles with selected rows are ever read)
     const unsigned char* q_tile_flag = nullptr;
-    // LayerNorm folded into the group-split GEMMs around it (glc_launch_gemm256s_gs; DESIGN.md "LayerNorm folded away").  The producer
+    // LayerNorm folded into the group-split GEMMs around it (glc_launch_gemm256s_gs; docs/LOG_r01-r05.md "LayerNorm folded away").  The producer
     // (EPI_RESID) writes the RAW sum (GS rows, C) plus per-row partial (sum, squared deviations from the block mean) of each 64-column block to ln_part
     // [Mpad][N / 64]; glc_launch_ln_stats turns them into (mean, rstd) per row.  A consumer whose A rows are such raw rows gets
     // a_stats [Mpad] + ln_c [N]: W then holds W . diag(gamma), ln_c[n] = sum_k W'[n][k], bias[n] = sum_k beta[k] W[n][k] + b[n], and the

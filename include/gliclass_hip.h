@@ -156,7 +156,7 @@ int glc_debug_set_attention_impl(glc_engine* e, int impl);
  * kernel).  mode 0 off, 1 auto (default: forwards large enough to fill the chip), 2 whenever the shapes allow (tests). */
 int glc_debug_set_group_split(glc_engine* e, int mode);
 int glc_debug_last_forward_group_split(const glc_engine* e);
-/* MX cross-term pipeline: every projection of the full layers as a_hi*w_hi in f16 MFMAs + both cross terms in ONE
+/* MX cross-term pipeline (docs/LOG_r01-r05.md §3e): every projection of the full layers as a_hi*w_hi in f16 MFMAs + both cross terms in ONE
  * block-scaled fp8 MFMA, on "GX" rows.  Needs the GX weight copies, i.e. an engine created under GLICLASS_MX=1 (selected) or =build. */
 int glc_debug_set_mx(glc_engine* e, int on);
 int glc_debug_last_forward_mx(const glc_engine* e);

@@ -1,5 +1,5 @@
 """Developer tool (GPU): the per-wave band kernel with split fragments (impl 2) against the oracle; GLC_ATTN_SPLIT_LEAN=1 picks the lean loop
-(the instantiation hipcc miscompiles when its SLP vectoriser is on)."""
+(docs/LOG_r01-r05.md section 2: the instantiation hipcc miscompiles when its SLP vectoriser is on)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

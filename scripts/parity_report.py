@@ -1,6 +1,6 @@
 """Developer tool (GPU): measured parity of every committed fixture (tests/golden/*.npz, generated from HF DebertaV2Model /
 Qwen2Model) per operand type: max |sigmoid(logit) - golden prob| and max hidden-state error on attended rows.
-The tests assert bounds; this prints the actual values for DESIGN.md §2."""
+The tests assert bounds; this prints the actual values for docs/LOG_r01-r05.md §2."""
 import glob, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

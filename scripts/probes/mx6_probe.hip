@@ -1,5 +1,5 @@
 // Probe (developer, standalone; round 4): the cross terms of a split product as ONE block-scaled MFMA on e2m3 (fp6) parts with per-block
-// e8m0 scales — the format DESIGN.md §9 names as the next step — next to today's e4m3 parts with a fixed exponent.  Pins, on gfx950:
+// e8m0 scales — the format docs/LOG_r01-r05.md §9 names as the next step — next to today's e4m3 parts with a fixed exponent.  Pins, on gfx950:
 //   * v_cvt_scalef32_2xpk16_fp6_f32: order of the 32 packed values (MEASURED: interleaved — value 2 i = src0[i], value 2 i + 1 = src1[i]) and
 //     result = e2m3(src / scale);
 //   * v_mfma_scale_f32_32x32x64_f8f6f4 with cbsz = blgp = 2: lane (row, h) supplies 32 fp6 values in six registers = k slots 32 h .. 32 h + 31,

@@ -1,6 +1,6 @@
 // Developer probe (GPU): operand layout, scale semantics and issue rate of the gfx950 block-scaled MFMA
 //   v_mfma_scale_f32_16x16x128_f8f6f4  (fp8 e4m3 operands, e8m0 block scales)
-// against the f16 16x16x32 MFMA — the building block of the "low-precision correction terms" idea.
+// against the f16 16x16x32 MFMA — the building block of the "low-precision correction terms" idea (docs/LOG_r01-r05.md §9).
 //   hipcc --offload-arch=gfx950 -O3 scripts/probes/mx_probe.hip -o /tmp/mx_probe && /tmp/mx_probe
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,5 +1,5 @@
 // Developer probe (GPU, round 3): how fast can a workgroup stream L2-resident operand rows into LDS?  The GEMM's loop is bound by its
-// LDS-DMA stream; this compares, on the GEMM's access shape (8 waves, 1 KiB per wave-instruction = 8 rows x 128 B,
+// LDS-DMA stream (docs/LOG_r01-r05.md §3e); this compares, on the GEMM's access shape (8 waves, 1 KiB per wave-instruction = 8 rows x 128 B,
 // a 64 KiB stage = 256 rows x 128 B x two operands, every CU re-reading buffers that fit the L2), per CU and second:
 //   mode 0  global_load_lds_dwordx4 (LDS-DMA), one 64 KiB stage in flight, vmcnt(0) + barrier per stage  (what gemm256x does)
 //   mode 1  the same with two stages in flight (ring of 2 x 64 KiB)

@@ -1,7 +1,7 @@
 """Developer tool (GPU): bitwise comparison of the product build against a build of every HIP translation unit with
 `-mllvm -amdgpu-waitcnt-forcezero` (the compiler waits for every counter before every instruction).  Identical logits on every case =
 no result of the product build depends on a wait the compiler left out (the class of bug behind round 1's "lean loop + split operands"
-miscompare).  usage: waitcnt_screen.py <path to the forcezero libgliclass_hip.so>   (scripts/build_forcezero.sh builds it)"""
+miscompare, docs/LOG_r01-r05.md §2).  usage: waitcnt_screen.py <path to the forcezero libgliclass_hip.so>   (scripts/build_forcezero.sh builds it)"""
 import os, sys, subprocess, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -14,7 +14,7 @@ shard across GPUs).
 Tolerances on per-label probabilities.  The acceptance bar is 1e-3 (north_star; the reference's own check,
 /root/reference/ONNX_CONVERTING/test_onnx.py:30).  The DEFAULT mode (GLICLASS_DTYPE=f32: fp32 data, split-f16 MFMA products) is
 asserted at 1e-4, ten times inside it.  f16 / bf16 are opt-in throughput modes: their operand rounding alone exceeds the bar on
-these synthetic models, so they are asserted at their measured envelopes and never used as a parity claim.
+these synthetic models (docs/LOG_r01-r05.md §2), so they are asserted at their measured envelopes and never used as a parity claim.
 """
 import numpy as np
 import pytest
@@ -26,6 +26,8 @@ TOL_DEFAULT_MODE = 1e-4      # split-f16 projections (GLICLASS_MX=0, and every f
 TOL_MX = 5e-4          # MX arithmetic of large forwards.  Observed worst case 2.4e-4 (soaks of round 5: 7273 + 5051 shapes on the MX pipeline, profiles/r05/soak_*.txt) / 1.8e-4 (profiles/r05/mx_margin_probe.txt: short rows, S = 256-320 —
                         # ~1.0e-4 from the GX-row projections + ~0.8e-4 from the MX-tile attention); asserted at half the bar = 2.1x that (round 4 asserted 3e-4 = 1.36x: a flake
                         # waiting for a seed) against the bar (1e-3, /root/reference/ONNX_CONVERTING/test_onnx.py:30)
+TOL_MX_LONG = 3e-4     # ... and on the shapes of BASELINE.json this file runs (c2 ... c5: S >= 512), where the MX arithmetic measures 1e-5 ... 1.2e-4 (profiles/r06/fullsize_values.txt) (rows of 1024+ tokens average the
+                        # operand noise out): asserted 3x inside that, so that a 2x precision regression of the headline shape fails here although it would pass TOL_MX
 ENVELOPE = {"f16": 1e-2, "bf16": 6e-2}
 
 
@@ -33,8 +35,8 @@ def sig(x):
     return 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
 
 
-def _tol(dtype):
-    return TOL_MX if dtype == "f32" else ENVELOPE[dtype]
+def _tol(dtype, long_rows=True):
+    return TOL_MX_LONG if dtype == "f32" else ENVELOPE[dtype]
 
 
 def _check_rows_vs_oracle(cfg, w, ids, mask, got, rows, tol):
@@ -104,7 +106,7 @@ def test_c3_base_b64_s1024(dtype, c_generated_weights):
         eng.set_length_buckets(1)                                       # one forward of M = 65 536 rows, as the bench runs it
         got = eng.forward(ids, mask)
         assert got.shape == (B, Cn) and np.isfinite(got).all()
-        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [0, 37, 63], _tol(dtype))
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [0, 37, 63], _tol(dtype, True))
         print(f"c3 {dtype}: max |prob - oracle| on 3 rows = {err:.2e} (bar {BAR})")
         if dtype == "f32":
             assert err <= BAR and eng.last_mx()                     # the default arithmetic of this shape: MX cross-term projections
@@ -112,12 +114,12 @@ def test_c3_base_b64_s1024(dtype, c_generated_weights):
             exact = eng.forward(ids, mask)
             assert not eng.last_mx()
             e2 = _check_rows_vs_oracle(cfg, w, ids, mask, exact, [0, 37, 63], TOL_DEFAULT_MODE)
-            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX    # all 512 probabilities, mode against mode
+            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX_LONG    # all 512 probabilities, mode against mode
             print(f"c3 f32, GLICLASS_MX=0: {e2:.2e}; MX vs split over all 512 probabilities {np.abs(sig(got) - sig(exact)).max():.2e}")
             eng.set_mx(True)
             # the WHOLE batch against the oracle once (all 64 rows = 512 probabilities; ~1 minute of host cores)
-            e_all = _check_rows_vs_oracle(cfg, w, ids, mask, got, list(range(B)), TOL_MX)
-            print(f"c3 f32: all {B} rows vs the oracle: max |prob - oracle| = {e_all:.2e} (asserted {TOL_MX}, bar {BAR})")
+            e_all = _check_rows_vs_oracle(cfg, w, ids, mask, got, list(range(B)), TOL_MX_LONG)
+            print(f"c3 f32: all {B} rows vs the oracle: max |prob - oracle| = {e_all:.2e} (asserted {TOL_MX_LONG}, bar {BAR})")
         # row independence across the batch: the upper half alone (M = 32 768: other tile counts, same rows)
         half = eng.forward(ids[32:], mask[32:])
         assert np.abs(sig(half) - sig(got[32:])).max() <= (1e-5 if dtype == "f32" else 5e-3)
@@ -149,10 +151,10 @@ def test_c3_default_mode_other_weight_seeds(seed, c_generated_weights):
         eng.set_mx(False)
         exact = eng.forward(ids, mask)
         d = float(np.abs(sig(got) - sig(exact)).max())
-        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [11], TOL_MX)
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [11], TOL_MX_LONG)
         e2 = _check_rows_vs_oracle(cfg, w, ids, mask, exact, [11], TOL_DEFAULT_MODE)
         print(f"c3 f32 seed {seed}: MX vs split over 512 probabilities {d:.2e}; row 11 vs oracle: MX {err:.2e}, split {e2:.2e}")
-        assert d <= TOL_MX
+        assert d <= TOL_MX_LONG
     finally:
         eng.close()
 
@@ -175,12 +177,12 @@ def test_c3_shape_with_other_scorers(scorer, c_generated_weights):
         eng.set_length_buckets(1)
         got = eng.forward(ids, mask)
         assert got.shape == (B, Cn) and np.isfinite(got).all() and eng.last_mx()
-        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [5, 58], TOL_MX)
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [5, 58], TOL_MX_LONG)
         eng.set_mx(False)
         exact = eng.forward(ids, mask)
         d = float(np.abs(sig(got) - sig(exact)).max())
         print(f"c3 {scorer}: rows 5, 58 vs oracle {err:.2e}; MX vs split over 512 probabilities {d:.2e}; logit range [{got.min():.2f}, {got.max():.2f}]")
-        assert d <= TOL_MX
+        assert d <= TOL_MX_LONG
     finally:
         eng.close()
 
@@ -209,7 +211,7 @@ def test_c4_large_shard_b32_s1024(dtype, c_generated_weights):
             assert not eng.last_mx()
             e2 = _check_rows_vs_oracle(cfg, w, ids, mask, exact, [5], TOL_DEFAULT_MODE)
             print(f"c4 shard f32, GLICLASS_MX=0: {e2:.2e}; MX vs split over all {B * Cn} probabilities {np.abs(sig(got) - sig(exact)).max():.2e}")
-            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX
+            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX_LONG
             eng.set_mx(True)
         quarter = eng.forward(ids[8:16], mask[8:16])
         assert np.abs(sig(quarter) - sig(got[8:16])).max() <= (1e-5 if dtype == "f32" else 5e-3)
@@ -251,8 +253,8 @@ def test_c4_global_batch_256_as_eight_shards_on_one_gpu(c_generated_weights):
         d = float(np.abs(sig(whole) - sig(stitched)).max())
         print(f"c4 global batch: 8 stitched shards vs one piece, max |prob diff| = {d:.2e}")
         assert d <= 1e-5
-        err = _check_rows_vs_oracle(cfg, w, ids, mask, stitched, [0, 100, 255], TOL_MX)
-        print(f"c4 global batch: rows 0 / 100 / 255 vs the oracle: {err:.2e} (asserted {TOL_MX}, bar {BAR})")
+        err = _check_rows_vs_oracle(cfg, w, ids, mask, stitched, [0, 100, 255], TOL_MX_LONG)
+        print(f"c4 global batch: rows 0 / 100 / 255 vs the oracle: {err:.2e} (asserted {TOL_MX_LONG}, bar {BAR})")
         lo, hi = shard_rows(B, G, 5)
         again = eng.forward(ids[lo:hi], mask[lo:hi])                       # behind the one-piece forward instead of behind shard 4
         assert np.abs(sig(again) - sig(parts[5])).max() <= 1e-6
@@ -281,10 +283,10 @@ def test_c5_decoder_b16_s2048(dtype, c_generated_weights):
         # (f32: the two-row forward is small enough to take the plain-fp32 row format and the 128-tile kernels, the batch the
         #  group-split format and the 256-tile kernels: same arithmetic, other summation order — both sit ~1e-5 from the oracle)
         # (round 3: the batch runs the MX cross-term projections, the two-row forward the split-f16 ones)
-        assert np.abs(sig(pair) - sig(got[6:8])).max() <= (TOL_MX if dtype == "f32" else 2e-2)
+        assert np.abs(sig(pair) - sig(got[6:8])).max() <= (TOL_MX_LONG if dtype == "f32" else 2e-2)
         if dtype == "f32":                                               # one whole row of 2048 tokens against the oracle
             w = c_generated_weights(spec, cfg)
-            err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [3], TOL_MX)
+            err = _check_rows_vs_oracle(cfg, w, ids, mask, got, [3], TOL_MX_LONG)
             print(f"c5 f32: max |prob - oracle| on 1 row = {err:.2e} (bar {BAR})")
             assert was_mx
             eng.set_mx(False)                                            # the split-f16 projections (GLICLASS_MX=0): ten times inside the bar
@@ -292,6 +294,6 @@ def test_c5_decoder_b16_s2048(dtype, c_generated_weights):
             assert not eng.last_mx()
             e2 = _check_rows_vs_oracle(cfg, w, ids, mask, exact, [3], TOL_DEFAULT_MODE)
             print(f"c5 f32, GLICLASS_MX=0: {e2:.2e}; MX vs split over all {B * Cn} probabilities {np.abs(sig(got) - sig(exact)).max():.2e}")
-            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX
+            assert np.abs(sig(got) - sig(exact)).max() <= TOL_MX_LONG
     finally:
         eng.close()

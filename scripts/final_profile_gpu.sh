@@ -22,7 +22,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 $BENCH > "$OUT/pmc_write.log" 2>&1; echo "write rc=$?"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o pmc -- python3 $BENCH > "$OUT/pmc_sq.log" 2>&1; echo "sq rc=$?"
 # (round 6, review item 4) second SQ pass + the clock: what the pipe waits for, per kernel — issue stalls, LDS, vector memory, MFMA / VALU co-execution
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -o pmc -- python3 $BENCH > "$OUT/pmc_sq2.log" 2>&1; echo "sq2 rc=$?"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_FLAT SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -o pmc -- python3 $BENCH > "$OUT/pmc_sq2.log" 2>&1; echo "sq2 rc=$?"
 cd "$REPO"
 python3 scripts/summarize_prof.py "$OUT" f32 base:64:1024 "$COMMIT" > "$OUT/summary.txt" 2>&1
 python3 scripts/pipe_account.py "$OUT" "$COMMIT" > "$OUT/pipe_account.txt" 2>&1

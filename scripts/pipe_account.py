@@ -19,7 +19,7 @@ for sub in ("pmc_sq", "pmc_sq2"):
                 seen.add(r["Dispatch_Id"])
                 d = dur[n]; d[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); d[1] += 1
 print("commit", commit, "(profiled passes: the chip clocks lower than in the un-profiled bench line; shares are what to read)")
-print(f"{'kernel':64s} {'us':>8s} {'GHz':>5s} {'MFMA busy':>9s} {'co-exec':>8s} {'parked':>7s} {'issue st.':>9s} {'LDS st.':>8s} {'VALU act':>8s} {'LDS act':>8s} {'VMEM act':>8s}")
+print(f"{'kernel':64s} {'us':>8s} {'GHz':>5s} {'MFMA busy':>9s} {'co-exec':>8s} {'parked':>7s} {'issue st.':>9s} {'LDS st.':>8s} {'VALU act':>8s} {'LDS act':>8s} {'FLAT act':>8s}")
 for n, cs in sorted(acc.items(), key=lambda kv: -dur[kv[0]][0]):
     if not any(t in n for t in ("attn_", "gemm256")) or not dur[n][1]:
         continue
@@ -29,6 +29,6 @@ for n, cs in sorted(acc.items(), key=lambda kv: -dur[kv[0]][0]):
     wc = g("SQ_WAVE_CYCLES")
     pct = lambda x: f"{100.0 * x:6.1f} %"
     print(f"{n:64s} {us:8.1f} {g('GRBM_GUI_ACTIVE') / 8.0 / (us * 1e3):5.2f} {pct(g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024.0 / kc):>9s} {pct(g('SQ_VALU_MFMA_COEXEC_CYCLES') / 1024.0 / kc):>8s} "
-          f"{pct(g('SQ_WAIT_ANY') / wc):>7s} {pct(g('SQ_WAIT_INST_ANY') / wc):>9s} {pct(g('SQ_WAIT_INST_LDS') / wc):>8s} {pct(g('SQ_ACTIVE_INST_VALU') / wc):>8s} {pct(g('SQ_ACTIVE_INST_LDS') / wc):>8s} {pct(g('SQ_ACTIVE_INST_VMEM') / wc):>8s}")
+          f"{pct(g('SQ_WAIT_ANY') / wc):>7s} {pct(g('SQ_WAIT_INST_ANY') / wc):>9s} {pct(g('SQ_WAIT_INST_LDS') / wc):>8s} {pct(g('SQ_ACTIVE_INST_VALU') / wc):>8s} {pct(g('SQ_ACTIVE_INST_LDS') / wc):>8s} {pct(g('SQ_ACTIVE_INST_FLAT') / wc):>8s}")
 print("columns: us = average launch duration in the counter pass; GHz = GRBM_GUI_ACTIVE / 8 / duration; MFMA busy / co-exec = share of a SIMD's cycles with the matrix pipe busy /")
-print("with matrix and vector instructions executing together; parked (SQ_WAIT_ANY), issue stalls (SQ_WAIT_INST_ANY), LDS stalls, VALU / LDS / VMEM instruction activity = shares of the waves' cycles")
+print("with matrix and vector instructions executing together; parked (SQ_WAIT_ANY), issue stalls (SQ_WAIT_INST_ANY), LDS stalls, VALU / LDS / FLAT (global loads, LDS-DMA) instruction activity = shares of the waves' cycles")

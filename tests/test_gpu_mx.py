@@ -255,7 +255,9 @@ def test_resident_position_blocks_bit_identical_to_per_tile_requests():
     if not os.path.exists(dev):
         pytest.skip("developer library not built (make -C gliclass/c_amd DEV=1 devlib)")
     env = dict(os.environ, GLC_HIP_SO=dev, GLC_REPS="0", GLC_SHAPES="16x1024,8x512,3x192,2x64,5x640,2x1536")
-    for va, vb in ((128, 128 | 131072), (128 | 2048, 128 | 2048 | 131072)):
+    # ... and round 6's form of the loop (ready-made offset table, planar position tables, descending c2p ring) against round 5's (variant bit 20): the same
+    # products and sums in another instruction stream
+    for va, vb in ((128, 128 | 131072), (128 | 2048, 128 | 2048 | 131072), (128, 128 | 1048576), (128 | 2048, 128 | 2048 | 1048576)):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "attn_variant_ab.py"), str(va), str(vb)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.count("identical True") == 12, (va, vb, r.stdout[-2000:], r.stderr[-2000:])
 

@@ -1,1 +1,3 @@
-timeout -k 10 900 python3 -m pytest tests/test_gpu_mx.py -q -x -k "resident" 2>&1 | tail -3
+OUT=gpurun_out/r06; mkdir -p $OUT
+V=gliclass/c_amd/variants
+bash scripts/ab_so.sh - $V/libgliclass_hip_gx_max-ilp.so $V/libgliclass_hip_gx_iterative-ilp.so > $OUT/ab_gemm_sched.txt 2>&1; cat $OUT/ab_gemm_sched.txt

@@ -1,3 +1,2 @@
-OUT=gpurun_out/r06; mkdir -p $OUT
-V=gliclass/c_amd/variants
-bash scripts/ab_so.sh - $V/libgliclass_hip_gx_max-ilp.so $V/libgliclass_hip_gx_iterative-ilp.so > $OUT/ab_gemm_sched.txt 2>&1; cat $OUT/ab_gemm_sched.txt
+timeout -k 10 1100 python3 -m pytest tests -q -x -m gpu 2>&1 | tail -4
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5

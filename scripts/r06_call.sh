@@ -1,2 +1,2 @@
-timeout -k 10 1100 python3 -m pytest tests -q -x -m gpu 2>&1 | tail -4
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+OUT=gpurun_out/r06; mkdir -p $OUT
+timeout -k 10 600 python3 scripts/parity_report.py > $OUT/parity_report.txt 2>&1; cat $OUT/parity_report.txt | tail -20

@@ -22,6 +22,7 @@
 // quad), the V third D[m][n].  Epilogues as gemm256s.hip (LDS-staged 16-byte stores, LayerNorm fold, residual prefetch), reading and
 // writing GX rows where that kernel has GS rows.
 #include <stdlib.h>
+#include <type_traits>
 #include "glc_common.h"
 #include "glc_kernels.h"
 #include "glc_layout.h"
@@ -43,6 +44,8 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 #ifndef GLC_GX_W_AUX
 #define GLC_GX_W_AUX 0
 #endif
+
+
 // AUX: the cache-policy bits of the request (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
 template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
@@ -64,10 +67,16 @@ __device__ __forceinline__ void x_tile_of_block(const GemmArgs& p, int ntn, int&
     }
 }
 
-template <int EPI, bool VMODE>
+// W128 (round 6; the launcher takes it for the large bias / GELU / SwiGLU / residual shapes): the same tile by FOUR waves, one per SIMD with 512 registers (the
+// 256 accumulator registers in AGPRs — hipcc's default; -amdgpu-mfma-vgpr-form would fill the loop with accumulator copies), each a 128 x 128 sub-tile = 16 blocks.  One in-order wave overlaps its MFMAs with its own loads when they alternate in program
+// order (profiles/r06/overlap_bisect.txt): per 32-group the wave issues F = 32 x 32x32x16 f16 with the group's fp8 fragment reads between them, then X = 16 scaled
+// 32x32x64 with the NEXT group's f16 fragment reads and its 16 DMA pieces of the group after that between them — every fragment register is loaded one phase
+// (1024 matrix-pipe cycles) before its use and dies with its phase, so no fragment is double-buffered (a16 / w16 / xa / xw: 128 registers), ONE barrier per group.
+// LDS reads per group and CU 128 KiB instead of 192; requests enter the vector-memory path one per MFMA gap instead of in bursts.
+template <int EPI, bool VMODE, bool W128 = false>
 __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, int ntn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm_outer = W128 ? (wave >> 1) : (wave >> 2), wn_outer = W128 ? (wave & 1) : (wave & 3);
     const int c32 = lane & 31, h = lane >> 5;
     const int K = p.K, N = p.N;
 
@@ -91,7 +100,7 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     const unsigned char* fw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = wave * 32 + i * 8 + lrow8;
+        const int row = wave * (W128 ? 64 : 32) + i * 8 + lrow8;
         const int lc = pch ^ ((row >> 1) & 7);
         fa[i] = A + (size_t)(m0 + row) * rsb + lc * 16;
         fw[i] = W + (size_t)(n0 + row) * rsb + lc * 16;
@@ -110,24 +119,98 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     };
     auto stage_fl = [&](int grp) { stage_a(grp); stage_w(grp); };
 
-    f32x16 acc[4][2];
+    f32x16 accs[W128 ? 2 : 1][4][2];          // W128: [column half ch][row block][column block of the half] — the epilogue below runs once per half
+#pragma unroll
+    for (int ch = 0; ch < (W128 ? 2 : 1); ++ch)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) accs[ch][i][j][r] = 0.f;
 
     // fragment read offsets inside a slot
     const int hsw = (c32 >> 1) & 7;
     constexpr int LINEF = LINE;
-    const int arow = (wm * 128 + c32) * LINEF, wrow = (wn * 64 + c32) * LINEF;
+    const int arow = (wm_outer * 128 + c32) * LINEF, wrow = (wn_outer * (W128 ? 128 : 64) + c32) * LINEF;
     const int ck0 = ((0 + h) ^ hsw) * 16, ck1 = ((2 + h) ^ hsw) * 16;       // f16 k-steps 0 / 1: logical chunks h / 2 + h
     const int cx0 = ((4 + 2 * h) ^ hsw) * 16, cx1 = ((5 + 2 * h) ^ hsw) * 16;       // the fp8 parts of elements 16 h .. 16 h + 7 / + 8 .. + 15
     // e8m0 scales (one per operand, every block): A rows (activations, exponent 0) carry the 2^-SHIFT, W rows their 2^-ws
     const int sc_a = 127 - GLC_GX_SHIFT - p.act_sc;        // e8m0 scale of the A blocks: 2^-(SHIFT + sc) (glc_common.h)
     const int sc_w = 127 - p.mx_ws;
 
+    if constexpr (W128) {
+        f16x8 a16[4][2], w16[4][2];
+        i32x8 xa[4], xw[4];
+        auto slot_a = [&](int grp) -> unsigned char* { return smem256x + ((2 * grp) & (NSLOT - 1)) * STAGE; };
+        auto slot_w = [&](int grp) -> unsigned char* { return smem256x + ((2 * grp + 1) & (NSLOT - 1)) * STAGE; };
+        // piece q = 0 .. 15 of this wave's 64 A rows (q < 8) and 64 W rows of group grp
+        auto dma_piece = [&](int grp, int q) __attribute__((always_inline)) {
+            const int i = q & 7;
+            const size_t o = (size_t)grp * LINE + (size_t)(i >> 1) * 16 * rsb;
+            if (q < 8) glds16<GLC_GX_A_AUX>(fa[i & 1] + o, slot_a(grp) + (wave * 64 + i * 8) * LINE);
+            else glds16<GLC_GX_W_AUX>(fw[i & 1] + o, slot_w(grp) + (wave * 64 + i * 8) * LINE);
+        };
+        // fragment read r = 0 .. 15 of a group: the f16 k-steps (r < 8: W blocks, r >= 8: A blocks; two reads per block) ...
+        auto rd_f16 = [&](int grp, int r) __attribute__((always_inline)) {
+            const int b = (r & 7) >> 1, ks = r & 1;
+            if (r < 8) w16[b][ks] = *reinterpret_cast<const f16x8*>(slot_w(grp) + wrow + b * 32 * LINEF + (ks ? ck1 : ck0));
+            else a16[b][ks] = *reinterpret_cast<const f16x8*>(slot_a(grp) + arow + b * 32 * LINEF + (ks ? ck1 : ck0));
+        };
+        // ... and the fp8 operands (two 16-byte chunks each)
+        auto rd_x = [&](int grp, int r) __attribute__((always_inline)) {
+            const int b = (r & 7) >> 1, half = r & 1;
+            const unsigned char* q0 = (r < 8 ? slot_w(grp) + wrow : slot_a(grp) + arow) + b * 32 * LINE + (half ? cx1 : cx0);
+            const i32x4 t = *reinterpret_cast<const i32x4*>(q0);
+            i32x8& d = r < 8 ? xw[b] : xa[b];
+            d[4 * half] = t[0]; d[4 * half + 1] = t[1]; d[4 * half + 2] = t[2]; d[4 * half + 3] = t[3];
+        };
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dma_piece(0, q);
+        if (ng > 1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dma_piece(1, q);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rd_f16(0, r);
+        // one group; M1 / M2 (compile time: the tail is peeled, a branch inside a phase would let hipcc sink the MFMAs behind the loads): groups s + 1 / s + 2 exist
+        auto step = [&](const int s, auto m1, auto m2) __attribute__((always_inline)) {
+            constexpr bool M1 = decltype(m1)::value, M2 = decltype(m2)::value;
+            // ---- F(s): a_hi w_hi of group s; its fp8 fragments are read underneath ----
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int ks = k >> 4, i = (k >> 2) & 3, j = k & 3;
+                f32x16& a = accs[j >> 1][i][j & 1];
+                if (!VMODE) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[j][ks], a16[i][ks], a, 0, 0, 0);      // D[n][m]
+                else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[i][ks], w16[j][ks], a, 0, 0, 0);            // D[m][n]
+                if ((k & 1) == 0) rd_x(s, k >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // group s + 1 (requested during X(s - 1)) has landed; every wave has read the last of group s: its slots are free
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- X(s): both cross terms of group s; the f16 fragments of group s + 1 are read and group s + 2 is requested underneath ----
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = k >> 2, j = k & 3;
+                f32x16& a = accs[j >> 1][i][j & 1];
+                if (!VMODE) a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xw[j], xa[i], a, 0, 0, 0, sc_w, 0, sc_a);
+                else a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[i], xw[j], a, 0, 0, 0, sc_a, 0, sc_w);
+                if constexpr (M1) rd_f16(s + 1, k);
+                if constexpr (M2) dma_piece(s + 2, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int s = 0; s + 2 < ng; ++s) step(s, std::true_type{}, std::true_type{});
+        if (ng > 1) step(ng - 2, std::true_type{}, std::false_type{});
+        step(ng - 1, std::false_type{}, std::false_type{});
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // every wave is through its last fragment read: the ring becomes the epilogue's staging space
+    } else {
+    const int wm = wm_outer;
+    f32x16 (&acc)[4][2] = accs[0];
     f16x8 a16[4][2], w16[2][2];
     i32x8 xa[4], xw[2];
     
@@ -205,10 +288,14 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
     for (int s = 0; s < ng; ++s) { sub(s, 0); sub(s, 1); }
     if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the late group's last barrier
     }
-    
+    }
 
     // ---------------- epilogue ----------------
-    {
+    // (W128: the wave's 128 x 128 as two 128 x 64 halves through the code of the 8-wave tiles — wave (wm, wn) there = (wave >> 1, 2 (wave & 1) + ch) here)
+#pragma unroll
+    for (int ch = 0; ch < (W128 ? 2 : 1); ++ch) {
+    const int wm = wm_outer, wn = W128 ? 2 * wn_outer + ch : wn_outer;
+    f32x16 (&acc)[4][2] = accs[ch];
     typedef f16_t T;
     typedef __attribute__((ext_vector_type(8))) T vec8T;
     const float* __restrict__ bias = p.bias;
@@ -516,6 +603,9 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
 
 template <int EPI, bool VMODE>
 __global__ __launch_bounds__(512, 2) void gemm256x_kernel(GemmArgs p, int n_tile0, int ntn) { gemm256x_tile<EPI, VMODE>(p, n_tile0, ntn); }
+// four waves, one per SIMD, 128 x 128 per wave (W128 above)
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256w_kernel(GemmArgs p, int n_tile0, int ntn) { gemm256x_tile<EPI, false, true>(p, n_tile0, ntn); }
 // Decoder QKV with the RoPE / MX-tile epilogue in ONE launch: the N-tiles of the V heads (nt >= nqk) run the transposed tile (c5: 7 + 1 N-tiles x
 // 128 M-tiles = 4 full rounds of the chip; as two launches the V heads' 128 workgroups would be a fifth, half-empty round)
 __global__ __launch_bounds__(512, 2) void gemm256x_qkvr_kernel(GemmArgs p, int nqk, int ntn) {
@@ -539,6 +629,20 @@ template <int EPI, bool VMODE> const char* launch_x(hipStream_t st, const GemmAr
     { constexpr int nbv = (GLC_GX_NB) > 0 ? (GLC_GX_NB) : 1;          // build-time A/B of the tile order (scripts/gemm_cache_policy_ab.sh; profiles/r05/gemm_cache_policy.txt)
       if ((a.Mpad / TM) % 8 == 0) b.n_group = (GLC_GX_NB) > 0 && ntn % nbv == 0 ? nbv : 0; }
 #endif
+    // Wave-tile choice (round 6, measured in the forwards of c3 / c4 / c5: profiles/r06/gemm_w128.txt): the one-wave-per-SIMD 128 x 128 tile reads a third less
+    // LDS per MAC and pays its own request issue; it wins where the K loop and the tile count amortise its double epilogue — N K >= 768 x 3072 (FFN1 / FFN2
+    // of every encoder shape: -2...-4 %; the decoder's gate|up, down and o_proj: -4...-12 %) — and loses below (attn-out of base / large: +1...+3 %) and on the
+    // QKV epilogues (more registers than it has left: spills).  GLC_GEMM_W128 = 0 / 1 (developer builds) forces the 8-wave / the one-wave tile.
+    if constexpr (!VMODE && (EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_RESID || EPI == EPI_SWIGLU)) {
+        static const int w128_env = glc_dev_env("GLC_GEMM_W128") ? atoi(glc_dev_env("GLC_GEMM_W128")) : -1;
+        const bool big = (long long)a.N * a.K >= 768LL * 3072LL;
+        if (w128_env == 1 || (w128_env < 0 && big)) {
+            static std::atomic<unsigned> lds_okw{0};
+            if (!glc_raise_lds_limit(gemm256w_kernel<EPI>, lds_bytes, lds_okw)) return "gemm256x: cannot raise the dynamic LDS limit";
+            hipLaunchKernelGGL((gemm256w_kernel<EPI>), dim3(grid), dim3(256), lds_bytes, st, b, n_tile0, ntn);
+            return nullptr;
+        }
+    }
     hipLaunchKernelGGL((gemm256x_kernel<EPI, VMODE>), dim3(grid), dim3(512), lds_bytes, st, b, n_tile0, ntn);
     return nullptr;
 }

@@ -27,7 +27,7 @@ def test_product_library_ships_only_shipping_kernel_instantiations():
     assert ks, "no kernel names found in the library"
     text = "\n".join(ks)
     # rejected experiments live in csrc/dev/ and are not linked
-    for gone in ("attn_mx2_kernel", "gemm256w_kernel", "to_gy_kernel", "gy_to_f32_kernel"):
+    for gone in ("attn_mx2_kernel", "to_gy_kernel", "gy_to_f32_kernel"):
         assert gone not in text, gone
     # band kernel on MX tiles: <NW, ABL = 0, DIAG = false, RECOMP = true, FIXQ = true, XROT = true, DIET = true> only
     mx = [k for k in ks if "attn_mx_kernel<" in k]
@@ -37,6 +37,9 @@ def test_product_library_ships_only_shipping_kernel_instantiations():
     # MX GEMM: two template parameters (epilogue, transposed tile), nothing else
     gx = [k for k in ks if "gemm256x_kernel<" in k]
     assert gx and all(re.search(r"gemm256x_kernel<\d, (true|false)>\(", k) for k in gx), gx
+    # ... and (round 6) its one-wave-per-SIMD tile for the large bias / GELU / residual / SwiGLU shapes: one template parameter (the epilogue), nothing else
+    gw = [k for k in ks if "gemm256w_kernel<" in k]
+    assert len(gw) == 4 and all(re.search(r"gemm256w_kernel<[0124]>\(", k) for k in gw), gw
     # workgroup-shared split-f16 attention: no stamped (DIAG) and no two-MFMA timing build (NMM = 2)
     for k in ks:
         m = re.search(r"attn_wg_kernel<([^>]*)>", k)

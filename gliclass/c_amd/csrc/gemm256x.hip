@@ -46,6 +46,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 #endif
 
 
+
 // AUX: the cache-policy bits of the request (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
 template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
@@ -145,11 +146,16 @@ __device__ __forceinline__ void gemm256x_tile(const GemmArgs& p, int n_tile0, in
         auto slot_a = [&](int grp) -> unsigned char* { return smem256x + ((2 * grp) & (NSLOT - 1)) * STAGE; };
         auto slot_w = [&](int grp) -> unsigned char* { return smem256x + ((2 * grp + 1) & (NSLOT - 1)) * STAGE; };
         // piece q = 0 .. 15 of this wave's 64 A rows (q < 8) and 64 W rows of group grp
+        // (the request in its scalar-base form: wave-uniform base + a 32-bit lane offset that never changes — no 64-bit address arithmetic per lane and piece)
+        const unsigned voffs[2] = {(unsigned)((size_t)lrow8 * rsb + (pch ^ (((wave * 64 + lrow8) >> 1) & 7)) * 16), (unsigned)((size_t)(8 + lrow8) * rsb + (pch ^ (((wave * 64 + 8 + lrow8) >> 1) & 7)) * 16)};
+        const unsigned char* const ubA = A + (size_t)(m0 + wave * 64) * rsb;
+        const unsigned char* const ubW = W + (size_t)(n0 + wave * 64) * rsb;
         auto dma_piece = [&](int grp, int q) __attribute__((always_inline)) {
             const int i = q & 7;
-            const size_t o = (size_t)grp * LINE + (size_t)(i >> 1) * 16 * rsb;
-            if (q < 8) glds16<GLC_GX_A_AUX>(fa[i & 1] + o, slot_a(grp) + (wave * 64 + i * 8) * LINE);
-            else glds16<GLC_GX_W_AUX>(fw[i & 1] + o, slot_w(grp) + (wave * 64 + i * 8) * LINE);
+            const unsigned char* ub = (q < 8 ? ubA : ubW) + (size_t)grp * LINE + (size_t)(i >> 1) * 16 * rsb;
+            unsigned char* l = (q < 8 ? slot_a(grp) : slot_w(grp)) + (wave * 64 + i * 8) * LINE;
+            const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)l;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(voffs[i & 1]), "s"(ub) : "memory");
         };
         // fragment read r = 0 .. 15 of a group: the f16 k-steps (r < 8: W blocks, r >= 8: A blocks; two reads per block) ...
         auto rd_f16 = [&](int grp, int r) __attribute__((always_inline)) {
